@@ -1,0 +1,42 @@
+# Builds the product library (HIP, gfx950) and the test oracle.
+#   make            libdoppler_hip.so + oracle
+#   make lib        doppler_amd/lib/libdoppler_hip.so only
+#   make oracle     oracle/liboracle.so, oracle/check_sincosf, oracle/_ref (if reference mounted)
+ROCM    ?= /opt/rocm
+HIPCC   ?= $(ROCM)/bin/hipcc
+ARCH    ?= gfx950
+CSRC    := doppler_amd/csrc
+LIBDIR  := doppler_amd/lib
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
+            -Wall -Wno-unused-function -Iinclude
+
+LIB := $(LIBDIR)/libdoppler_hip.so
+OBJS := $(LIBDIR)/dpx_kernels.o $(LIBDIR)/dpx_api.o $(LIBDIR)/dpx_planner.o
+
+all: lib oracle
+
+lib: $(LIB)
+
+$(LIBDIR)/dpx_kernels.o: $(CSRC)/dpx_kernels.hip $(CSRC)/dpx_sincos.cuh $(CSRC)/dpx_types.h include/doppler_hip.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/dpx_api.o: $(CSRC)/dpx_api.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h include/doppler_hip.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(LIBDIR)/dpx_planner.o: $(CSRC)/dpx_planner.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h
+	@mkdir -p $(LIBDIR)
+	g++ -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -Wl,-rpath,$(ROCM)/lib -Wl,-soname,libdoppler_hip.so
+
+oracle:
+	$(MAKE) -C oracle all
+
+clean:
+	rm -rf $(LIBDIR)
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib oracle clean

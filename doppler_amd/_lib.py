@@ -1,0 +1,85 @@
+"""ctypes binding of include/doppler_hip.h (doppler_amd/lib/libdoppler_hip.so).
+
+Loading never falls back to anything: a missing library or a missing symbol
+raises ImportError naming the build command.
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdoppler_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "doppler_hip.h")
+
+FMT_I16, FMT_F32 = 0, 1
+BUFFER_SIZE = 8192
+
+OK, ERR_ARG, ERR_BLOCK_LEN, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_PLAN = 0, -1, -2, -3, -4, -5, -6
+
+
+class Segment(C.Structure):
+    _fields_ = [("n_samples", C.c_uint64), ("shift_hz", C.c_float)]
+
+
+class Stretch(C.Structure):
+    _fields_ = [("first", C.c_uint64), ("count", C.c_uint64), ("ratio", C.c_float),
+                ("n_start", C.c_uint32), ("period", C.c_uint32), ("lut_len", C.c_uint32)]
+
+
+def declared_symbols():
+    """Every function include/doppler_hip.h declares (parsed from the header text)."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dpx_[a-z0-9_]+)\s*\(", text)))
+
+
+_vp, _sz, _u32, _u64, _i, _f = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int, C.c_float
+_P = C.POINTER
+
+_SIGNATURES = {
+    "dpx_abi_version": (_i, []),
+    "dpx_last_error": (C.c_char_p, []),
+    "dpx_device_count": (_i, [_P(_i)]),
+    "dpx_ctx_create": (_i, [_i, _P(_vp)]),
+    "dpx_ctx_destroy": (None, [_vp]),
+    "dpx_convert_iqi16_to_complex": (_i, [_vp, _vp, _sz, _vp, _sz, _P(_sz)]),
+    "dpx_convert_iqf32_to_complex": (_i, [_vp, _vp, _sz, _vp, _sz, _P(_sz)]),
+    "dpx_shift_frequency": (_i, [_vp, _vp, _sz, _P(_u32), _f, _u32, _vp]),
+    "dpx_pack_iqi16": (_i, [_vp, _vp, _sz, _vp, _sz]),
+    "dpx_shift_block": (_i, [_vp, _vp, _sz, _i, _vp, _sz, _i, _P(_u32), _f, _u32, _P(_sz)]),
+    "dpx_ccexpf_imag": (_i, [_vp, _vp, _sz]),
+    "dpx_find_reset": (_i, [_f, _u32, _u32, _u64, _P(_u32), _P(_i)]),
+    "dpx_samplenum_after": (_i, [_f, _u32, _u32, _u64, _P(_u32)]),
+    "dpx_plan_describe": (_i, [_P(Segment), _sz, _u32, _u32, _i, _P(Stretch), _sz, _P(_sz), _P(_u32)]),
+    "dpx_plan_const": (_i, [_vp, _f, _u32, _u32, _u64, _P(_vp)]),
+    "dpx_plan_segments": (_i, [_vp, _P(Segment), _sz, _u32, _u32, _P(_vp)]),
+    "dpx_plan_n_samples": (_i, [_vp, _P(_u64)]),
+    "dpx_plan_final_samplenum": (_i, [_vp, _P(_u32)]),
+    "dpx_plan_destroy": (None, [_vp]),
+    "dpx_run_device": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
+    "dpx_debug_copy": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "dpx_set_tuning": (_i, [_vp, _i, _i, _i]),
+    "dpx_set_libm_contraction": (_i, [_vp, _i]),
+    "dpx_malloc": (_i, [_vp, _sz, _P(_vp)]),
+    "dpx_free": (_i, [_vp, _vp]),
+    "dpx_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "dpx_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "dpx_synchronize": (_i, [_vp]),
+}
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "doppler_amd: %s is missing. Build it with `make lib` (hipcc --offload-arch=gfx950) or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise ImportError("doppler_amd: %s does not export %s; rebuild with `make lib`" % (LIB_PATH, name))
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib

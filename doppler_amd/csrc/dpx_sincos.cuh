@@ -1,0 +1,141 @@
+// dpx_sincos.cuh — device sincosf that is bit-identical to glibc 2.35's.
+//
+// The reference builds its corrector with libm: src/dsp.rs:121-122 ->
+// src/complex.c:35 cexpf(0 + i*theta), which for a zero real part is
+// (cosf(theta), sinf(theta)) from glibc's sincosf (Szabolcs Nagy's
+// optimized-routines algorithm: double-precision polynomial, three argument
+// ranges).  "Within 1 ulp" of the output cannot be met with a different
+// sincos (theta reaches tens to thousands of radians, and the complex multiply
+// cancels), so this file evaluates the same double-precision operation
+// sequence, with the same products fused as the x86-64 FMA build of libm fuses
+// them (FMA=true) or none fused (FMA=false, the SSE2 build).
+//
+// Structure for a 64-wide wavefront: the three glibc ranges are folded so that
+// lanes do not diverge in the common case —
+//   * |y| < 2^-12 ("tiny") and inf/nan are per-lane selects at the end;
+//   * the "< pi/4" range is evaluated through the quadrant-reduction formula,
+//     which yields quadrant 0 and an unchanged argument there (n*hpi = 0), so
+//     it is exactly the direct polynomial;
+//   * only |y| >= 120 takes a real branch (skipped when no lane needs it).
+// The two polynomial tables of glibc (cos / -cos) and the sign[] table are
+// replaced by exact sign flips of the results (round-to-nearest is symmetric).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace dpx {
+
+// 4/pi in overlapping 32-bit windows (glibc __inv_pio4), 192 bits
+__device__ __constant__ const uint32_t kInvPio4[24] = {
+    0xa2,       0xa2f9,     0xa2f983,   0xa2f9836e, 0xf9836e4e, 0x836e4e44,
+    0x6e4e4415, 0x4e441529, 0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1,
+    0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0, 0x34ddc0db, 0xddc0db62,
+    0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041,
+};
+
+template <bool FMA>
+__device__ __forceinline__ double mad(double a, double b, double c)
+{
+    if constexpr (FMA) {
+        return __builtin_fma(a, b, c);
+    } else {
+        double p = a * b;   // contract(off): two roundings
+        return p + c;
+    }
+}
+
+// sin and cos of y, bit-identical to glibc 2.35 sincosf (see header comment).
+template <bool FMA>
+__device__ __forceinline__ void sincosf_glibc(float y, float &sn, float &cs)
+{
+    constexpr double HPI_INV = 0x1.45F306DC9C883p+23;   // 2/pi * 2^24
+    constexpr double HPI = 0x1.921FB54442D18p0;         // pi/2
+    constexpr double PI63 = 0x1.921FB54442D18p-62;
+    constexpr double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5,
+                     C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+    constexpr double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7,
+                     S3 = -0x1.994eb3774cf24p-13;
+
+    const uint32_t xi = __float_as_uint(y);
+    const uint32_t top = (xi >> 20) & 0x7ffu;          // abstop12
+    const double x = (double)y;
+
+    // ranges "< pi/4" and "< 120": n = round(x * 2/pi) via scaled int, xr = x - n*pi/2
+    double xr;
+    uint32_t quad, sidx;
+    {
+        // clamp keeps the conversion defined for lanes that will take another range
+        const double xc = (top < 0x42fu) ? x : 0.0;
+        const double r = xc * HPI_INV;
+        const int n = (__double2int_rz(r) + 0x800000) >> 24;
+        const double nd = (double)n;
+        if constexpr (FMA) xr = __builtin_fma(-nd, HPI, xc);
+        else               xr = xc - nd * HPI;
+        quad = (uint32_t)n;
+        sidx = (uint32_t)n;
+    }
+    if (top >= 0x42fu && top < 0x7f8u) {
+        // |y| >= 120: exact 32x96-bit fixed-point product with 4/pi
+        const uint32_t *arr = &kInvPio4[(xi >> 26) & 15u];
+        const uint32_t shift = (xi >> 23) & 7u;
+        uint32_t m = (xi & 0xffffffu) | 0x800000u;
+        m <<= shift;
+        uint64_t res0 = (uint32_t)(m * arr[0]);
+        const uint64_t res1 = (uint64_t)m * arr[4];
+        const uint64_t res2 = (uint64_t)m * arr[8];
+        res0 = (res2 >> 32) | (res0 << 32);
+        res0 += res1;
+        const uint64_t n = (res0 + (1ULL << 61)) >> 62;
+        res0 -= n << 62;
+        xr = (double)(int64_t)res0 * PI63;
+        quad = (uint32_t)n;
+        sidx = (uint32_t)n + (xi >> 31);
+    }
+
+    const double x2 = xr * xr;
+    const double x3 = x2 * xr;
+    const double x4 = x2 * x2;
+    const double c2 = mad<FMA>(x2, C4, C3);
+    const double s1 = mad<FMA>(x2, S3, S2);
+    const double c1 = mad<FMA>(x2, C1, C0);
+    const double x5 = x3 * x2;
+    const double x6 = x4 * x2;
+    const double s = mad<FMA>(x3, S1, xr);
+    const double c = mad<FMA>(x4, C2, c1);
+    uint32_t fs = __float_as_uint((float)mad<FMA>(x5, s1, s));
+    uint32_t fc = __float_as_uint((float)mad<FMA>(x6, c2, c));
+
+    // glibc: argument * sign[sidx&3] with sign = {+,-,-,+}; table[1] (sidx&2) is -cos
+    fs ^= ((sidx + 1u) & 2u) << 30;
+    fc ^= (sidx & 2u) << 30;
+    // odd quadrant: sin and cos trade places
+    const bool swap = (quad & 1u) != 0;
+    float rs = __uint_as_float(swap ? fc : fs);
+    float rc = __uint_as_float(swap ? fs : fc);
+
+    if (top < 0x398u) {          // |y| < 2^-12: sin = y, cos = 1
+        rs = y;
+        rc = 1.0f;
+    }
+    if (top >= 0x7f8u) {         // inf / nan
+        rs = rc = y - y;
+    }
+    sn = rs;
+    cs = rc;
+}
+
+// The corrector of dsp.rs:121-122 for counter value n:
+//   theta = (-2*PI) * (ratio * (n as f32))   — each product rounded to f32,
+//   (c, s) = cexpf(0 + i*theta) = (cosf(theta), sinf(theta)).
+// ratio = shift_hz / (samplerate as f32) is rounded once on the host.
+template <bool FMA>
+__device__ __forceinline__ void corrector(float ratio, uint32_t n, float &c, float &s)
+{
+    const float p = __fmul_rn(ratio, (float)n);          // u32 -> f32 rounds to nearest even
+    const float theta = __fmul_rn(-6.28318530717958647692f, p);
+    sincosf_glibc<FMA>(theta, s, c);
+}
+
+}  // namespace dpx

@@ -1,0 +1,201 @@
+"""Context / Plan objects over the C ABI (include/doppler_hip.h)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+complex32 = np.dtype([("re", "<f4"), ("im", "<f4")])
+_FMT = {"i16": _lib.FMT_I16, "f32": _lib.FMT_F32, _lib.FMT_I16: _lib.FMT_I16, _lib.FMT_F32: _lib.FMT_F32}
+BYTES_PER_SAMPLE = {_lib.FMT_I16: 4, _lib.FMT_F32: 8}
+
+
+class DspError(AssertionError):
+    """The C ABI returned an error. `code` is the dpx_status value; DPX_ERR_BLOCK_LEN is what
+    the reference reports as an `assert!` panic (src/dsp.rs:87, src/dsp.rs:103)."""
+
+    def __init__(self, code, message):
+        super().__init__("dpx error %d: %s" % (code, message))
+        self.code = code
+
+
+def _lib_handle():
+    from . import lib
+    return lib
+
+
+def check(rc):
+    if rc != _lib.OK:
+        raise DspError(rc, _lib_handle().dpx_last_error().decode("utf-8", "replace"))
+
+
+def fmt_code(fmt):
+    try:
+        return _FMT[fmt]
+    except KeyError:
+        raise DspError(_lib.ERR_ARG, "unknown IQ format %r (use 'i16' or 'f32')" % (fmt,))
+
+
+def as_bytes(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint8).reshape(-1)
+
+
+class Context:
+    """One GPU. Creation fails (DspError, DPX_ERR_NO_DEVICE) when no gfx950 device is usable."""
+
+    def __init__(self, device=0):
+        self._lib = _lib_handle()
+        self._h = C.c_void_p()
+        check(self._lib.dpx_ctx_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.dpx_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_tuning(self, blocks_per_cu=0, unroll=0, variant=0):
+        check(self._lib.dpx_set_tuning(self._h, blocks_per_cu, unroll, variant))
+
+    def set_libm_contraction(self, fma=True):
+        check(self._lib.dpx_set_libm_contraction(self._h, 1 if fma else 0))
+
+    # ---- device memory helpers (for callers without torch)
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        check(self._lib.dpx_malloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        check(self._lib.dpx_free(self._h, C.c_void_p(ptr)))
+
+    def h2d(self, dptr, host):
+        b = as_bytes(host)
+        check(self._lib.dpx_memcpy_h2d(self._h, C.c_void_p(dptr), b.ctypes.data, b.size))
+
+    def d2h(self, host, dptr):
+        assert host.flags["C_CONTIGUOUS"]
+        check(self._lib.dpx_memcpy_d2h(self._h, host.ctypes.data, C.c_void_p(dptr), host.nbytes))
+
+    def synchronize(self):
+        check(self._lib.dpx_synchronize(self._h))
+
+    def debug_copy(self, d_in, d_out, nbytes, stream=0):
+        check(self._lib.dpx_debug_copy(self._h, C.c_void_p(d_in), C.c_void_p(d_out), nbytes, C.c_void_p(stream)))
+
+    # ---- plans
+    def plan_const(self, shift_hz, samplerate, n_samples, samplenum=0):
+        return Plan(self, [(int(n_samples), float(shift_hz))], samplerate, samplenum)
+
+    def plan_segments(self, segments, samplerate, samplenum=0):
+        """segments: iterable of (n_samples, shift_hz)."""
+        return Plan(self, list(segments), samplerate, samplenum)
+
+
+class Plan:
+    """Closed-form counter description of a stream, resident on the GPU; run() launches the fused kernel."""
+
+    def __init__(self, ctx, segments, samplerate, samplenum=0):
+        self._lib = _lib_handle()
+        self.ctx = ctx
+        arr = (_lib.Segment * max(1, len(segments)))()
+        for i, (n, hz) in enumerate(segments):
+            arr[i].n_samples = int(n)
+            arr[i].shift_hz = float(hz)
+        self._h = C.c_void_p()
+        check(self._lib.dpx_plan_segments(ctx.handle, arr, len(segments), int(samplerate), int(samplenum),
+                                          C.byref(self._h)))
+        n = C.c_uint64()
+        check(self._lib.dpx_plan_n_samples(self._h, C.byref(n)))
+        self.n_samples = n.value
+        sn = C.c_uint32()
+        check(self._lib.dpx_plan_final_samplenum(self._h, C.byref(sn)))
+        self.final_samplenum = sn.value
+
+    def run(self, d_in, in_fmt, d_out, out_fmt, stream=0):
+        """Asynchronous launch on `stream` (a hipStream_t value; 0 = default stream)."""
+        check(self._lib.dpx_run_device(self._h, C.c_void_p(d_in), fmt_code(in_fmt), C.c_void_p(d_out),
+                                       fmt_code(out_fmt), C.c_void_p(stream)))
+
+    def run_tensors(self, x, out, in_fmt, out_fmt):
+        """Convenience for torch tensors on this context's GPU: launches on torch's current stream."""
+        import torch
+        assert x.is_cuda and out.is_cuda and x.is_contiguous() and out.is_contiguous()
+        need_in = self.n_samples * BYTES_PER_SAMPLE[fmt_code(in_fmt)]
+        need_out = self.n_samples * BYTES_PER_SAMPLE[fmt_code(out_fmt)]
+        if x.numel() * x.element_size() < need_in or out.numel() * out.element_size() < need_out:
+            raise DspError(_lib.ERR_CAPACITY, "tensor smaller than the plan's %d samples" % self.n_samples)
+        self.run(x.data_ptr(), in_fmt, out.data_ptr(), out_fmt, torch.cuda.current_stream(x.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.dpx_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = None
+
+
+def default_context():
+    """Process-wide context on device LOCAL_RANK (or 0), created on first use."""
+    global _default
+    if _default is None:
+        import os
+        _default = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default
+
+
+def plan_describe(segments, samplerate, samplenum=0, variant=0):
+    """Host-only: the closed-form stretches for (n_samples, shift_hz) segments.
+    Returns (list of dict, final_samplenum). Needs no GPU."""
+    lib = _lib_handle()
+    segs = list(segments)
+    arr = (_lib.Segment * max(1, len(segs)))()
+    for i, (n, hz) in enumerate(segs):
+        arr[i].n_samples = int(n)
+        arr[i].shift_hz = float(hz)
+    n_out = C.c_size_t()
+    fin = C.c_uint32()
+    cap = 64
+    while True:
+        out = (_lib.Stretch * cap)()
+        check(lib.dpx_plan_describe(arr, len(segs), int(samplerate), int(samplenum), int(variant), out, cap,
+                                    C.byref(n_out), C.byref(fin)))
+        if n_out.value <= cap:
+            break
+        cap = n_out.value
+    res = [dict(first=s.first, count=s.count, ratio=np.float32(s.ratio), n_start=s.n_start, period=s.period,
+                lut_len=s.lut_len) for s in out[: n_out.value]]
+    return res, fin.value
+
+
+def find_reset(shift_hz, samplerate, n_start, max_scan):
+    lib = _lib_handle()
+    n = C.c_uint32()
+    found = C.c_int()
+    check(lib.dpx_find_reset(float(shift_hz), int(samplerate), int(n_start), int(max_scan), C.byref(n), C.byref(found)))
+    return n.value if found.value else None
+
+
+def samplenum_after(shift_hz, samplerate, samplenum0, k):
+    lib = _lib_handle()
+    n = C.c_uint32()
+    check(lib.dpx_samplenum_after(float(shift_hz), int(samplerate), int(samplenum0), int(k), C.byref(n)))
+    return n.value

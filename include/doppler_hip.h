@@ -1,0 +1,175 @@
+/*
+ * doppler_hip.h — C ABI of the MI355X (gfx950) Doppler-correction hot path.
+ *
+ * This shared library (libdoppler_hip.so) stands behind the reference's operator
+ * boundary `doppler::dsp` (reference src/lib.rs:35) exactly where the reference
+ * already crosses into native code: src/dsp.rs:40-42 declares
+ *     extern { pub fn ccexpf(z: *mut LiquidComplex32); }
+ * and build.rs:28 links libcomplex.a.  A maintainer swaps that static library
+ * for this one and binds the entry points below (the Rust `extern "C"` block is
+ * shown in INTEGRATION.md).  Plain C types only: pointers, sizes, fixed-width
+ * integers, float.  No panics cross the boundary: where the reference
+ * `assert!`s (dsp.rs:87, dsp.rs:103) these functions return DPX_ERR_BLOCK_LEN.
+ *
+ * All arithmetic runs on the GPU in hand-written HIP kernels.  There is NO CPU
+ * fallback: without a usable gfx950 device dpx_ctx_create fails with
+ * DPX_ERR_NO_DEVICE and nothing else can be called.
+ *
+ * Data is little-endian interleaved IQ: i16 = 4 bytes/sample, f32 = 8 bytes/sample.
+ * A context is bound to one GPU and is not thread-safe; distinct contexts are
+ * independent (one context per GPU / per process rank).
+ */
+#ifndef DOPPLER_HIP_H
+#define DOPPLER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPX_ABI_VERSION 1
+
+/* reference src/usage.rs:39-42  enum DataType { F32, I16 } */
+#define DPX_FMT_I16 0
+#define DPX_FMT_F32 1
+
+/* reference src/main.rs:49  const BUFFER_SIZE: usize = 8192 */
+#define DPX_BUFFER_SIZE 8192
+
+enum dpx_status {
+    DPX_OK = 0,
+    DPX_ERR_ARG = -1,        /* null pointer, unknown format, bad size            */
+    DPX_ERR_BLOCK_LEN = -2,  /* byte length not a whole number of samples
+                                (the reference panics: dsp.rs:87, dsp.rs:103)      */
+    DPX_ERR_NO_DEVICE = -3,  /* no gfx950 GPU visible / device index out of range */
+    DPX_ERR_HIP = -4,        /* a HIP runtime call failed; see dpx_last_error()   */
+    DPX_ERR_CAPACITY = -5,   /* output buffer too small                           */
+    DPX_ERR_PLAN = -6        /* run does not match the plan (sample count, ...)   */
+};
+
+/* reference src/complex.c:28-31 RustComplex == src/dsp.rs:41 LiquidComplex32 ==
+ * num::complex::Complex<f32> memory layout */
+typedef struct { float re, im; } dpx_complex32;
+
+typedef struct dpx_ctx dpx_ctx;
+typedef struct dpx_plan dpx_plan;
+
+/* One constant-shift stretch of the stream (track mode: reference
+ * src/main.rs:156-184 changes shift_hz only between 8192-byte blocks). */
+typedef struct {
+    uint64_t n_samples;
+    float shift_hz;
+} dpx_segment;
+
+/* ------------------------------------------------------------------ context */
+int dpx_abi_version(void);
+const char *dpx_last_error(void);               /* thread-local message of the last failure */
+int dpx_device_count(int *count);
+int dpx_ctx_create(int device, dpx_ctx **ctx);  /* fails loudly without a gfx950 device */
+void dpx_ctx_destroy(dpx_ctx *ctx);
+
+/* ------------------------------------------- operator entry points (host I/O)
+ * Synchronous, host pointers in and out; staging, kernels and copies happen
+ * inside.  These are what the reference's FFI for this path binds. */
+
+/* replaces dsp.rs:85-99  convert_iqi16_to_complex(&[u8]) -> Vec<Complex<f32>> */
+int dpx_convert_iqi16_to_complex(dpx_ctx *ctx, const uint8_t *inbuf, size_t in_bytes,
+                                 dpx_complex32 *out, size_t out_cap, size_t *n_out);
+
+/* replaces dsp.rs:101-115 convert_iqf32_to_complex(&[u8]) -> Vec<Complex<f32>> */
+int dpx_convert_iqf32_to_complex(dpx_ctx *ctx, const uint8_t *inbuf, size_t in_bytes,
+                                 dpx_complex32 *out, size_t out_cap, size_t *n_out);
+
+/* replaces dsp.rs:117-134 shift_frequency(&[Complex<f32>], &mut u32, f32, u32) -> Vec<..>
+ * `samplenum` is the caller-owned counter of dsp.rs:125-130, updated in place. */
+int dpx_shift_frequency(dpx_ctx *ctx, const dpx_complex32 *inbuf, size_t n, uint32_t *samplenum,
+                        float shift_hz, uint32_t samplerate, dpx_complex32 *out);
+
+/* replaces main.rs:72-87: Complex<f32> -> LE i16 bytes, (x*32767.0) as i16 */
+int dpx_pack_iqi16(dpx_ctx *ctx, const dpx_complex32 *inbuf, size_t n, uint8_t *out, size_t out_cap);
+
+/* The whole body of the `shift` closure (main.rs:65-94) fused into one kernel:
+ * unpack -> mix -> pack, never materialising Complex<f32> in memory.  Any number
+ * of bytes (not limited to 8192); `samplenum` in/out as above. */
+int dpx_shift_block(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt,
+                    void *out, size_t out_cap, int out_fmt, uint32_t *samplenum,
+                    float shift_hz, uint32_t samplerate, size_t *n_samples_out);
+
+/* replaces complex.c:33-39 ccexpf for the only argument shape the path ever
+ * builds (dsp.rs:121: real part 0): z[k] <- cexpf(0 + i*z[k].im), in place. */
+int dpx_ccexpf_imag(dpx_ctx *ctx, dpx_complex32 *z, size_t n);
+
+/* ------------------------------------------------- host-side counter algebra
+ * Closed form of the counter rule dsp.rs:125-130 (pure host integer/f32 code). */
+
+/* first n >= n_start with fract(fl32(ratio*fl32(n))) == 0, scanning at most
+ * max_scan candidates; *found = 0 if none in range. ratio = shift_hz/(f32)samplerate. */
+int dpx_find_reset(float shift_hz, uint32_t samplerate, uint32_t n_start, uint64_t max_scan,
+                   uint32_t *n_reset, int *found);
+/* value of the counter after `k` samples starting from samplenum0 (constant shift) */
+int dpx_samplenum_after(float shift_hz, uint32_t samplerate, uint32_t samplenum0, uint64_t k,
+                        uint32_t *samplenum);
+
+/* One stretch of the stream in which the counter is a closed form of the
+ * sample index j (relative to `first`):  period == 0: n = n_start + j;
+ * period > 0: n = ((n_start - 1 + j) mod period) + 1.  lut_len > 0: the kernel
+ * keeps one period of correctors in LDS for this stretch. */
+typedef struct {
+    uint64_t first, count;
+    float ratio;
+    uint32_t n_start, period, lut_len;
+} dpx_stretch;
+
+/* Host-only (no device needed): the stretch list the planner derives for a
+ * segment list; writes at most `cap` entries, *n_out = total number. */
+int dpx_plan_describe(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
+                      uint32_t samplenum0, int variant, dpx_stretch *out, size_t cap,
+                      size_t *n_out, uint32_t *final_samplenum);
+
+/* ----------------------------------------------- bulk API (device pointers) */
+
+/* constant shift over n_samples starting with counter samplenum0 */
+int dpx_plan_const(dpx_ctx *ctx, float shift_hz, uint32_t samplerate, uint32_t samplenum0,
+                   uint64_t n_samples, dpx_plan **plan);
+/* piecewise-constant shift: consecutive segments, counter carried across them
+ * exactly as the reference carries `samplenr` (main.rs:60) across blocks */
+int dpx_plan_segments(dpx_ctx *ctx, const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
+                      uint32_t samplenum0, dpx_plan **plan);
+int dpx_plan_n_samples(const dpx_plan *plan, uint64_t *n_samples);
+int dpx_plan_final_samplenum(const dpx_plan *plan, uint32_t *samplenum);
+void dpx_plan_destroy(dpx_plan *plan);
+
+/* Launch the fused kernel on `hip_stream` (a hipStream_t; NULL = default stream).
+ * d_in / d_out are device pointers, 16-byte aligned, holding plan.n_samples
+ * samples in in_fmt / out_fmt.  Asynchronous: returns after the launch. */
+int dpx_run_device(dpx_plan *plan, const void *d_in, int in_fmt, void *d_out, int out_fmt,
+                   void *hip_stream);
+
+/* Same access pattern, no arithmetic: 16-byte non-temporal copy of n_bytes.
+ * Calibration only (profiles/: what the memory system gives a pure stream). */
+int dpx_debug_copy(dpx_ctx *ctx, const void *d_in, void *d_out, size_t n_bytes, void *hip_stream);
+
+/* Kernel-geometry knobs for measurement sweeps (0 keeps the current value).
+ * variant: 0 = auto (LDS table when the period fits, else on-the-fly sincos),
+ *          1 = force on-the-fly, 2 = force table (fails at run if it cannot). */
+int dpx_set_tuning(dpx_ctx *ctx, int blocks_per_cu, int unroll, int variant);
+
+/* Which build of glibc's sincosf the correctors reproduce bit-for-bit:
+ * fma = 1 (default): the FMA build libm selects on every x86-64 CPU with FMA+AVX2;
+ * fma = 0: the SSE2 build (differs on 34 of all 2^32 arguments). */
+int dpx_set_libm_contraction(dpx_ctx *ctx, int fma);
+
+/* --------------------------------------------- device memory helpers
+ * For callers without their own HIP runtime binding (ctypes tests, the CLI). */
+int dpx_malloc(dpx_ctx *ctx, size_t bytes, void **d_ptr);
+int dpx_free(dpx_ctx *ctx, void *d_ptr);
+int dpx_memcpy_h2d(dpx_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int dpx_memcpy_d2h(dpx_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int dpx_synchronize(dpx_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

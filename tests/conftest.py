@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure; oracle/)."""
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """A GPU context through the C ABI. Only gpu-marked tests may request it."""
+    import doppler_amd
+    c = doppler_amd.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    yield c
+    c.close()

@@ -1,0 +1,81 @@
+"""Measurement sweep for the fused kernel on one MI355X (development tool, not the bench contract).
+
+python tools/sweep.py [--n SAMPLES] [--iters K]
+Prints one line per (format pair, variant, unroll, blocks/CU): average kernel ms (HIP events on the
+launch stream) and algorithmic GB/s.  Also times the calibration copy kernel.
+"""
+import argparse
+import json
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+import doppler_amd  # noqa: E402
+
+BPS = {"i16": 4, "f32": 8}
+
+
+def time_launches(fn, iters, warmup=3):
+    st = torch.cuda.current_stream()
+    for _ in range(warmup):
+        fn()
+    st.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record(st)
+        fn()
+        b.record(st)
+    st.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return sum(ts) / len(ts), ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=268435456)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--pairs", default="i16:i16")
+    ap.add_argument("--shift", type=float, default=5000.0)
+    ap.add_argument("--rate", type=int, default=1024000)
+    ap.add_argument("--variants", default="0,1")
+    ap.add_argument("--unrolls", default="1,2,4,8")
+    ap.add_argument("--bpcs", default="4,8,16")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    ctx = doppler_amd.Context(0)
+    n = args.n
+    stream = torch.cuda.current_stream().cuda_stream
+    for pair in args.pairs.split(","):
+        it, ot = pair.split(":")
+        if it == "i16":
+            x = torch.randint(-23170, 23171, (2 * n,), dtype=torch.int16, device=dev)
+        else:
+            x = (torch.rand(2 * n, dtype=torch.float32, device=dev) * 2 - 1)
+        out = torch.empty(n * BPS[ot], dtype=torch.uint8, device=dev)
+        alg = n * (BPS[it] + BPS[ot])
+        if it == ot:
+            for bpc in [int(b) for b in args.bpcs.split(",")]:
+                ctx.set_tuning(bpc, 4, 3)
+                avg, med, mn = time_launches(lambda: ctx.debug_copy(x.data_ptr(), out.data_ptr(), n * BPS[it], stream), args.iters)
+                print(json.dumps({"kernel": "copy", "pair": pair, "bpc": bpc, "ms_avg": round(avg, 4), "ms_min": round(mn, 4),
+                                  "GBps_avg": round(alg / avg / 1e6, 1), "GBps_best": round(alg / mn / 1e6, 1)}), flush=True)
+        for variant in [int(v) for v in args.variants.split(",")]:
+            for unroll in [int(u) for u in args.unrolls.split(",")]:
+                for bpc in [int(b) for b in args.bpcs.split(",")]:
+                    ctx.set_tuning(bpc, unroll, variant if variant else 3)
+                    plan = ctx.plan_const(args.shift, args.rate, n)
+                    avg, med, mn = time_launches(lambda: plan.run(x.data_ptr(), it, out.data_ptr(), ot, stream), args.iters)
+                    print(json.dumps({"kernel": "shift", "pair": pair, "variant": variant, "unroll": unroll, "bpc": bpc,
+                                      "ms_avg": round(avg, 4), "ms_med": round(med, 4), "ms_min": round(mn, 4),
+                                      "GBps_avg": round(alg / avg / 1e6, 1), "GBps_best": round(alg / mn / 1e6, 1),
+                                      "Msps_avg": round(n / avg / 1e3, 0)}), flush=True)
+                    plan.close()
+        del x, out
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
