@@ -17,9 +17,11 @@ all: lib oracle
 
 lib: $(LIB)
 
+# -amdgpu-kernarg-preload-count=16: the first 16 dwords of kernel arguments arrive in SGPRs,
+# so the one-shot wavefronts issue their loads without an s_load round trip (see rows_kernel).
 $(LIBDIR)/dpx_kernels.o: $(CSRC)/dpx_kernels.hip $(CSRC)/dpx_sincos.cuh $(CSRC)/dpx_types.h include/doppler_hip.h
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -mllvm -amdgpu-kernarg-preload-count=16 -c $< -o $@
 
 $(LIBDIR)/dpx_api.o: $(CSRC)/dpx_api.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h include/doppler_hip.h
 	@mkdir -p $(LIBDIR)

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "dpx_find_reset": (_i, [_f, _u32, _u32, _u64, _P(_u32), _P(_i)]),
     "dpx_samplenum_after": (_i, [_f, _u32, _u32, _u64, _P(_u32)]),
     "dpx_plan_describe": (_i, [_P(Segment), _sz, _u32, _u32, _i, _P(Stretch), _sz, _P(_sz), _P(_u32)]),
+    "dpx_plan_simulate": (_i, [_P(Segment), _sz, _u32, _u32, _i, _i, _i, _vp, _vp, _u64]),
     "dpx_plan_const": (_i, [_vp, _f, _u32, _u32, _u64, _P(_vp)]),
     "dpx_plan_segments": (_i, [_vp, _P(Segment), _sz, _u32, _u32, _P(_vp)]),
     "dpx_plan_n_samples": (_i, [_vp, _P(_u64)]),

@@ -45,19 +45,32 @@ struct dpx_ctx {
     int device = -1;
     int n_cu = 0;
     bool fma = true;          // libm variant whose sincosf the kernels reproduce
-    int blocks_per_cu = 8;
-    int unroll = 4;
+    int block = 256;          // lanes per workgroup (128 or 256)
+    int vecs = 1;             // 4-sample groups per lane (1, 2 or 4)
     int variant = 0;
+    bool use_rows = true;     // false: tile kernel only (measurement A/B)
     hipStream_t stream = nullptr;   // internal stream of the host-pointer entry points
     void *stage_in = nullptr;
     void *stage_out = nullptr;
     size_t stage_in_cap = 0, stage_out_cap = 0;
+    struct DevPlan *scratch = nullptr;   // device side of the host-pointer operators' plans
+};
+
+// device image of a plan: stretch table | hint table | corrector-table pool, one allocation
+struct DevPlan {
+    void *buf = nullptr;
+    size_t cap = 0;
+    dpx::DevSeg *segs = nullptr;
+    uint32_t *hint = nullptr;
+    void *lut = nullptr;
 };
 
 struct dpx_plan {
     dpx_ctx *ctx = nullptr;
     dpx::PlanResult host;
-    dpx::DevSeg *d_segs = nullptr;
+    dpx::LaunchGeom geom;
+    bool fma = true;
+    DevPlan dev;
 };
 
 namespace {
@@ -83,25 +96,71 @@ int ensure_stage(dpx_ctx *ctx, size_t in_bytes, size_t out_bytes)
     return DPX_OK;
 }
 
-dpx::LaunchGeom geometry(const dpx_ctx *ctx, const dpx::PlanResult &plan)
+dpx::LaunchGeom geometry(const dpx_ctx *ctx)
 {
     dpx::LaunchGeom g;
-    g.unroll = ctx->unroll;
-    const uint64_t tile = (uint64_t)dpx::kBlock * dpx::kSamplesPerLane * g.unroll;
-    const uint64_t n_tiles = (plan.n_samples + tile - 1) / tile;
-    const uint64_t cap = (uint64_t)ctx->n_cu * ctx->blocks_per_cu;
-    g.grid = (int)(n_tiles < 1 ? 1 : (n_tiles < cap ? n_tiles : cap));
-    g.lds_bytes = plan.max_lut_len * (uint32_t)sizeof(float) * 2u;
+    g.block = ctx->block;
+    g.vecs = ctx->vecs;
     return g;
 }
 
-int upload_plan(dpx_plan *p)
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Upload stretch + hint tables and fill the corrector tables (async on `st`).
+// `plan` must have been finalize()d for geometry `g`.
+int materialize(dpx_ctx *ctx, const dpx::PlanResult &plan, DevPlan &dev, bool fma, hipStream_t st)
 {
-    const size_t bytes = p->host.segs.size() * sizeof(dpx::DevSeg);
-    if (bytes == 0) return DPX_OK;
-    DPX_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_segs), bytes));
-    DPX_HIP(hipMemcpy(p->d_segs, p->host.segs.data(), bytes, hipMemcpyHostToDevice));
+    const size_t seg_bytes = align256(plan.segs.size() * sizeof(dpx::DevSeg));
+    const size_t hint_bytes = align256(plan.hint.size() * sizeof(uint32_t));
+    const size_t lut_bytes = align256(plan.lut_entries * 8 + 64);
+    const size_t need = seg_bytes + hint_bytes + lut_bytes;
+    if (need > dev.cap) {
+        if (dev.buf) {
+            DPX_HIP(hipStreamSynchronize(st));
+            DPX_HIP(hipFree(dev.buf));
+        }
+        dev.buf = nullptr;
+        dev.cap = 0;
+        const size_t cap = need + need / 2;
+        DPX_HIP(hipMalloc(&dev.buf, cap));
+        dev.cap = cap;
+    }
+    char *base = static_cast<char *>(dev.buf);
+    dev.segs = reinterpret_cast<dpx::DevSeg *>(base);
+    dev.hint = reinterpret_cast<uint32_t *>(base + seg_bytes);
+    dev.lut = base + seg_bytes + hint_bytes;
+    DPX_HIP(hipMemcpyAsync(dev.segs, plan.segs.data(), plan.segs.size() * sizeof(dpx::DevSeg),
+                           hipMemcpyHostToDevice, st));
+    DPX_HIP(hipMemcpyAsync(dev.hint, plan.hint.data(), plan.hint.size() * sizeof(uint32_t),
+                           hipMemcpyHostToDevice, st));
+    for (const dpx::TableBuild &t : plan.tables) {
+        int rc = dpx::launch_build_lut(static_cast<char *>(dev.lut) + (size_t)t.off * 8, t.period, t.n_first,
+                                       t.n_entries, t.ratio, fma, st);
+        if (rc != DPX_OK) return fail(rc, "table build launch failed: %s", hipGetErrorString(hipGetLastError()));
+    }
     return DPX_OK;
+}
+
+// every launch of a finalized plan, asynchronously on `st`
+int run_plan(const dpx::PlanResult &plan, const DevPlan &dev, const void *d_in, int in_fmt, void *d_out,
+             int out_fmt, bool fma, const dpx::LaunchGeom &g, void *st)
+{
+    for (const dpx::Launch &ln : plan.launches) {
+        int rc;
+        if (ln.kind == 0)
+            rc = dpx::launch_rows(d_in, in_fmt, d_out, out_fmt, dev.segs, dev.lut, ln.rows, fma, st);
+        else
+            rc = dpx::launch_tiles(d_in, in_fmt, d_out, out_fmt, dev.segs, (uint32_t)plan.segs.size(), dev.hint,
+                                   dev.lut, ln.tiles, fma, g, st);
+        if (rc != DPX_OK) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    return DPX_OK;
+}
+
+void release(DevPlan &dev)
+{
+    if (dev.buf) (void)hipFree(dev.buf);
+    dev = DevPlan();
 }
 
 // shared body of the host-pointer operators: stage in, one fused launch, stage out
@@ -116,19 +175,19 @@ int run_host(dpx_ctx *ctx, const void *in, size_t n, int in_fmt, void *out, int 
         *samplenum = sn;
         return DPX_OK;
     }
+    const dpx::LaunchGeom g = geometry(ctx);
+    dpx::finalize(plan, g.tile(), ctx->use_rows);
     const size_t in_bytes = n * bytes_per_sample(in_fmt), out_bytes = n * bytes_per_sample(out_fmt);
-    const size_t seg_bytes = plan.segs.size() * sizeof(dpx::DevSeg);
-    int rc = ensure_stage(ctx, in_bytes + 64 + seg_bytes, out_bytes);
+    int rc = ensure_stage(ctx, in_bytes, out_bytes);
     if (rc != DPX_OK) return rc;
-    // stretch table rides behind the input in the same staging buffer (32-byte aligned)
-    const size_t seg_off = (in_bytes + 63) & ~(size_t)63;
-    dpx::DevSeg *d_segs = reinterpret_cast<dpx::DevSeg *>(static_cast<char *>(ctx->stage_in) + seg_off);
+    if (!ctx->scratch) ctx->scratch = new (std::nothrow) DevPlan;
+    if (!ctx->scratch) return fail(DPX_ERR_ARG, "out of host memory");
+    // the previous call synchronised the stream, so the scratch image is free to overwrite
+    rc = materialize(ctx, plan, *ctx->scratch, ctx->fma, ctx->stream);
+    if (rc != DPX_OK) return rc;
     DPX_HIP(hipMemcpyAsync(ctx->stage_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-    DPX_HIP(hipMemcpyAsync(d_segs, plan.segs.data(), seg_bytes, hipMemcpyHostToDevice, ctx->stream));
-    rc = dpx::launch_shift(ctx->stage_in, in_fmt, ctx->stage_out, out_fmt, d_segs,
-                           (uint32_t)plan.segs.size(), plan.n_samples, ctx->fma,
-                           geometry(ctx, plan), ctx->stream);
-    if (rc != DPX_OK) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    rc = run_plan(plan, *ctx->scratch, ctx->stage_in, in_fmt, ctx->stage_out, out_fmt, ctx->fma, g, ctx->stream);
+    if (rc != DPX_OK) return rc;
     DPX_HIP(hipMemcpyAsync(out, ctx->stage_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     DPX_HIP(hipStreamSynchronize(ctx->stream));
     *samplenum = sn;
@@ -191,20 +250,24 @@ void dpx_ctx_destroy(dpx_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stage_in) (void)hipFree(ctx->stage_in);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
+    if (ctx->scratch) {
+        release(*ctx->scratch);
+        delete ctx->scratch;
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
-int dpx_set_tuning(dpx_ctx *ctx, int blocks_per_cu, int unroll, int variant)
+int dpx_set_tuning(dpx_ctx *ctx, int block, int vecs, int variant)
 {
     if (!ctx) return fail(DPX_ERR_ARG, "ctx is null");
-    if (blocks_per_cu < 0 || blocks_per_cu > 64) return fail(DPX_ERR_ARG, "blocks_per_cu out of range");
-    if (unroll != 0 && unroll != 1 && unroll != 2 && unroll != 4 && unroll != 8)
-        return fail(DPX_ERR_ARG, "unroll must be 1, 2, 4 or 8");
-    if (variant < 0 || variant > 3) return fail(DPX_ERR_ARG, "variant out of range");
-    if (blocks_per_cu) ctx->blocks_per_cu = blocks_per_cu;
-    if (unroll) ctx->unroll = unroll;
-    ctx->variant = variant == 3 ? 0 : variant;
+    if (block != 0 && block != 128 && block != 256) return fail(DPX_ERR_ARG, "block must be 128 or 256");
+    if (vecs != 0 && vecs != 1 && vecs != 2) return fail(DPX_ERR_ARG, "vecs must be 1 or 2");
+    if (variant < 0 || variant > 4) return fail(DPX_ERR_ARG, "variant out of range");
+    if (block) ctx->block = block;
+    if (vecs) ctx->vecs = vecs;
+    ctx->use_rows = variant != 4;
+    ctx->variant = (variant == 3 || variant == 4) ? 0 : variant;
     return DPX_OK;
 }
 
@@ -334,7 +397,7 @@ int dpx_plan_describe(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
                       size_t *n_out, uint32_t *final_samplenum)
 {
     if ((n_segs && !segs) || !n_out || (cap && !out)) return fail(DPX_ERR_ARG, "bad argument");
-    static_assert(sizeof(dpx_stretch) == sizeof(dpx::DevSeg), "dpx_stretch mirrors DevSeg");
+    static_assert(sizeof(dpx_stretch) == sizeof(dpx::StretchView), "dpx_stretch mirrors the head of DevSeg");
     dpx::PlanResult plan;
     uint32_t sn = samplenum0;
     for (size_t i = 0; i < n_segs; ++i)
@@ -342,6 +405,27 @@ int dpx_plan_describe(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
     *n_out = plan.segs.size();
     for (size_t i = 0; i < plan.segs.size() && i < cap; ++i) memcpy(&out[i], &plan.segs[i], sizeof(dpx_stretch));
     if (final_samplenum) *final_samplenum = sn;
+    return DPX_OK;
+}
+
+int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
+                      uint32_t samplenum0, int block, int vecs, int variant,
+                      uint32_t *counters, uint8_t *writes, uint64_t n_samples)
+{
+    if ((n_segs && !segs) || !counters || !writes) return fail(DPX_ERR_ARG, "bad argument");
+    dpx::PlanResult plan;
+    uint32_t sn = samplenum0;
+    const int v = (variant == 3 || variant == 4) ? 0 : variant;
+    for (size_t i = 0; i < n_segs; ++i)
+        dpx::plan_append(plan, dpx::ratio_of(segs[i].shift_hz, samplerate), segs[i].n_samples, sn, v);
+    if (plan.n_samples != n_samples) return fail(DPX_ERR_PLAN, "segments hold %llu samples, buffers %llu",
+                                                 (unsigned long long)plan.n_samples, (unsigned long long)n_samples);
+    dpx::LaunchGeom g;
+    g.block = block ? block : 256;
+    g.vecs = vecs ? vecs : 1;
+    dpx::finalize(plan, g.tile(), variant != 4);
+    memset(writes, 0, n_samples);
+    dpx::simulate(plan, counters, writes);
     return DPX_OK;
 }
 
@@ -355,13 +439,23 @@ int dpx_plan_segments(dpx_ctx *ctx, const dpx_segment *segs, size_t n_segs, uint
     dpx_plan *p = new (std::nothrow) dpx_plan;
     if (!p) return fail(DPX_ERR_ARG, "out of host memory");
     p->ctx = ctx;
+    p->geom = geometry(ctx);
+    p->fma = ctx->fma;
     uint32_t sn = samplenum0;
     p->host.final_samplenum = sn;
     for (size_t i = 0; i < n_segs; ++i)
         dpx::plan_append(p->host, dpx::ratio_of(segs[i].shift_hz, samplerate), segs[i].n_samples, sn,
                          ctx->variant);
+    dpx::finalize(p->host, p->geom.tile(), ctx->use_rows);
     hipError_t e = hipSetDevice(ctx->device);
-    int rc = e == hipSuccess ? upload_plan(p) : fail(DPX_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    int rc = e == hipSuccess ? DPX_OK : fail(DPX_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    if (rc == DPX_OK && p->host.n_samples) {
+        rc = materialize(ctx, p->host, p->dev, p->fma, ctx->stream);
+        if (rc == DPX_OK) {
+            e = hipStreamSynchronize(ctx->stream);   // tables are complete before any user stream runs
+            if (e != hipSuccess) rc = fail(DPX_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
+        }
+    }
     if (rc != DPX_OK) {
         dpx_plan_destroy(p);
         return rc;
@@ -396,9 +490,9 @@ int dpx_plan_final_samplenum(const dpx_plan *plan, uint32_t *samplenum)
 void dpx_plan_destroy(dpx_plan *plan)
 {
     if (!plan) return;
-    if (plan->d_segs) {
+    if (plan->dev.buf) {
         (void)hipSetDevice(plan->ctx->device);
-        (void)hipFree(plan->d_segs);
+        release(plan->dev);
     }
     delete plan;
 }
@@ -410,20 +504,13 @@ int dpx_run_device(dpx_plan *plan, const void *d_in, int in_fmt, void *d_out, in
     if (plan->host.n_samples == 0) return DPX_OK;
     if (!d_in || !d_out) return fail(DPX_ERR_ARG, "null device pointer");
     if (((uintptr_t)d_in | (uintptr_t)d_out) & 15u) return fail(DPX_ERR_ARG, "device pointers must be 16-byte aligned");
-    int rc = dpx::launch_shift(d_in, in_fmt, d_out, out_fmt, plan->d_segs, (uint32_t)plan->host.segs.size(),
-                               plan->host.n_samples, plan->ctx->fma, geometry(plan->ctx, plan->host),
-                               hip_stream);
-    if (rc != DPX_OK) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
-    return DPX_OK;
+    return run_plan(plan->host, plan->dev, d_in, in_fmt, d_out, out_fmt, plan->fma, plan->geom, hip_stream);
 }
 
 int dpx_debug_copy(dpx_ctx *ctx, const void *d_in, void *d_out, size_t n_bytes, void *hip_stream)
 {
     if (!ctx || !d_in || !d_out || (n_bytes & 15u)) return fail(DPX_ERR_ARG, "bad argument");
-    const uint64_t n_vec = n_bytes / 16, tile = (uint64_t)dpx::kBlock * 4;
-    const uint64_t tiles = (n_vec + tile - 1) / tile, cap = (uint64_t)ctx->n_cu * ctx->blocks_per_cu;
-    const int grid = (int)(tiles < 1 ? 1 : (tiles < cap ? tiles : cap));
-    int rc = dpx::launch_copy(d_in, d_out, n_bytes, grid, hip_stream);
+    int rc = dpx::launch_copy(d_in, d_out, n_bytes, hip_stream);
     if (rc != DPX_OK) return fail(rc, "kernel launch failed");
     return DPX_OK;
 }

@@ -3,7 +3,7 @@
 // One pass over HBM replaces the reference's three passes per 8 KiB block
 // (unpack src/dsp.rs:85-115, mix src/dsp.rs:117-134, pack src/main.rs:72-94):
 //     load 16-byte vectors of interleaved IQ  ->  unpack in registers
-//     corrector(n) from an LDS table (one period) or evaluated on the fly
+//     corrector(n) from a precomputed table (one period) or evaluated on the fly
 //     complex multiply with the reference's unfused f32 operation order
 //     pack to i16 / f32  ->  16-byte stores
 // The kernel is HBM-bandwidth bound by design: 8 B/sample for i16->i16.
@@ -138,150 +138,248 @@ __device__ __forceinline__ uint32_t counter_at(const DevSeg &sg, uint64_t j)
     return (uint32_t)(((uint64_t)(sg.n_start - 1u) + j) % sg.period) + 1u;
 }
 
-// ------------------------------------------------------------- fused kernel
+// ---------------------------------------------------------------- the kernels
 //
-// Work decomposition: the stream is cut into tiles of BLOCK*4*U samples; tile t
-// goes to workgroup t mod gridDim (block-cyclic, so the whole grid sweeps one
-// contiguous window of HBM at a time).  A lane owns 4 consecutive samples per
-// vector and U vectors per tile, all U loads issued before the first use.
-template <int IN_FMT, int OUT_FMT, bool FMA, int U>
-__global__ __launch_bounds__(kBlock) void shift_kernel(const uint8_t *__restrict__ in,
-                                                       uint8_t *__restrict__ out,
-                                                       const DevSeg *__restrict__ segs,
-                                                       uint32_t n_segs, uint64_t n_samples)
+// Shape of the launch (measured, profiles/r01_membench.md): on MI355X a
+// 1 GiB -> 1 GiB stream runs at 6.6-6.7 TB/s when it is issued as one-shot
+// workgroups of 1-4 wavefronts that touch 1-4 KiB and exit, against 6.0-6.1 TB/s
+// for every persistent grid-stride shape tried, and every extra vector-memory
+// instruction per wavefront (a corrector table read) costs a few percent.  So:
+//   * no persistent loop, no LDS staging, tiny workgroups, addresses from
+//     blockIdx alone so the sample loads are issued first;
+//   * correctors of a periodic stretch are tabulated ONCE per plan in global
+//     memory (<= 64 KiB, L2-resident) by build_lut_kernel with the bit-exact
+//     sincos, never per workgroup;
+//   * rows kernel: the stream is viewed as a matrix whose row length is a
+//     multiple of the period, so the two rows a wavefront handles share one
+//     32-byte table read per lane and need no phase arithmetic.
+
+// ---- per-sample evaluation (ragged ranges and stretch boundaries)
+template <int IN_FMT, int OUT_FMT, bool FMA>
+__device__ __forceinline__ void one_sample(const uint8_t *in, uint8_t *out, const DevSeg *segs,
+                                           uint32_t n_segs, uint32_t si, uint64_t g)
 {
-    extern __shared__ float2 lut[];   // correctors (cos, sin) of one table period
-    constexpr uint32_t SPL = kSamplesPerLane;
-    constexpr uint32_t TILE = kBlock * SPL * U;
-    const uint32_t tid = threadIdx.x;
-    const uint64_t n_tiles = (n_samples + TILE - 1) / TILE;
+    while (si + 1 < n_segs && segs[si].first + segs[si].count <= g) ++si;
+    const DevSeg sx = segs[si];
+    float c, s, a, b, re, im;
+    corrector<FMA>(sx.ratio, counter_at(sx, g - sx.first), c, s);
+    load_one<IN_FMT>(in, g, a, b);
+    mix(a, b, c, s, re, im);
+    store_one<OUT_FMT>(out, g, re, im);
+}
 
-    uint32_t si = 0;           // current stretch (uniform across the workgroup)
-    uint32_t lut_owner = ~0u;  // stretch whose table is in LDS
+// ---- rows kernel: one wavefront, kRowsR rows of one tabulated periodic stretch
+template <int FMT> struct RowVec;   // S samples of one lane in one row: 16 bytes in
+template <> struct RowVec<DPX_FMT_I16> { static constexpr int S = 4; };
+template <> struct RowVec<DPX_FMT_F32> { static constexpr int S = 2; };
 
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t t0 = tile * TILE;
-        while (si + 1 < n_segs && segs[si].first + segs[si].count <= t0) ++si;
-        const DevSeg sg = segs[si];
-        const bool whole = (t0 + TILE <= n_samples) && (t0 >= sg.first) &&
-                           (t0 + TILE <= sg.first + sg.count);
-        if (whole) {
-            const uint64_t j0 = t0 - sg.first;
+// Argument order matters: the first 16 dwords are preloaded into SGPRs at wavefront
+// launch (-amdgpu-kernarg-preload-count=16), and they are exactly what the matrix
+// path needs — a one-shot wavefront issues its loads without waiting for any s_load.
+template <int IN_FMT, int OUT_FMT, bool FMA>
+__global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restrict__ in,
+                                                          uint8_t *__restrict__ out,
+                                                          const float2 *__restrict__ tab,   // table, origin = sample A
+                                                          uint64_t A, uint32_t L, uint32_t cols,
+                                                          uint64_t div_m, uint32_t div_s,
+                                                          uint32_t n_main,
+                                                          // ---- ragged path only (not preloaded)
+                                                          const DevSeg *__restrict__ segs,
+                                                          RowsArgs ra)
+{
+    constexpr int S = RowVec<IN_FMT>::S;
+    constexpr int R = kRowsR;
+    constexpr int IB = Fmt<IN_FMT>::kBytes, OB = Fmt<OUT_FMT>::kBytes;
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
 
-            // issue every load of this tile first: U x 16 B (i16) or 2U x 16 B (f32) per lane
-            Quad<IN_FMT> qin[U];
+    if (b < n_main) {
+        // (row group, column slice) = divmod(b, cols), exact magic-number division
+        const uint32_t rg = (uint32_t)(((uint64_t)b * div_m) >> div_s);
+        const uint32_t col = b - rg * cols;
+        const uint32_t cs0 = (col * kRowsLanes + lane) * S;   // first sample of this lane in the row
+        if (cs0 >= L) return;                                  // ragged last column slice
+        const uint64_t g0 = A + (uint64_t)rg * (R * (uint64_t)L) + cs0;
+
+        u32x4 q[R];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                qin[u] = load_quad<IN_FMT>(in, t0 + (uint64_t)(u * kBlock + tid) * SPL);
+        for (int r = 0; r < R; ++r)
+            q[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in + (g0 + (uint64_t)r * L) * IB));
 
-            if (sg.lut_len != 0) {
-                // ---- corrector table of one period in LDS
-                const uint32_t L = sg.lut_len;
-                if (lut_owner != si) {
-                    __syncthreads();   // previous table no longer in use
-                    for (uint32_t e = tid; e < L; e += kBlock) {
-                        float c, s;
-                        corrector<FMA>(sg.ratio, (e % sg.period) + 1u, c, s);
-                        lut[e] = make_float2(c, s);
-                    }
-                    __syncthreads();
-                    lut_owner = si;
-                }
-                const uint32_t tb = (uint32_t)(((uint64_t)(sg.n_start - 1u) + j0) % L);
-                const uint32_t step = (kBlock * SPL) % L;
-                uint32_t t = (tb + tid * SPL) % L;
+        // S correctors, shared by the R rows: table origin is sample A, so the index is cs0
+        const u32x4 *tp = reinterpret_cast<const u32x4 *>(tab + cs0);
+        u32x4 t[S / 2];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    Quad<OUT_FMT> qo;
+        for (int i = 0; i < S / 2; ++i) t[i] = tp[i];
+
 #pragma unroll
-                    for (int k = 0; k < (int)SPL; ++k) {
-                        uint32_t e = t + k;
-                        e = (e >= L) ? e - L : e;
-                        const float2 cs = lut[e];
-                        float a, b, re, im;
-                        quad_get<IN_FMT>(qin[u], k, a, b);
-                        mix(a, b, cs.x, cs.y, re, im);
-                        quad_set<OUT_FMT>(qo, k, re, im);
-                    }
-                    store_quad<OUT_FMT>(out, t0 + (uint64_t)(u * kBlock + tid) * SPL, qo);
-                    t += step;
-                    t = (t >= L) ? t - L : t;
+        for (int r = 0; r < R; ++r) {
+            float re[S], im[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                float a, bq;
+                if constexpr (IN_FMT == DPX_FMT_I16) unpack_i16(q[r][k], a, bq);
+                else { a = __uint_as_float(q[r][2 * k]); bq = __uint_as_float(q[r][2 * k + 1]); }
+                const float c = __uint_as_float(t[k >> 1][(k & 1) * 2]);
+                const float s = __uint_as_float(t[k >> 1][(k & 1) * 2 + 1]);
+                mix(a, bq, c, s, re[k], im[k]);
+            }
+            uint8_t *op = out + (g0 + (uint64_t)r * L) * OB;
+            if constexpr (OUT_FMT == DPX_FMT_I16) {
+                if constexpr (S == 4) {
+                    u32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = pack_i16(re[k], im[k]);
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(op));
+                } else {
+                    u32x2 o;
+                    o[0] = pack_i16(re[0], im[0]);
+                    o[1] = pack_i16(re[1], im[1]);
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x2 *>(op));
                 }
             } else {
-                // ---- corrector evaluated per sample (periodic with period >= 4, or linear)
-                const uint32_t P = sg.period;
-                uint32_t t, step;
-                if (P != 0) {
-                    const uint32_t tb = (uint32_t)(((uint64_t)(sg.n_start - 1u) + j0) % P);
-                    step = (kBlock * SPL) % P;
-                    t = (tb + tid * SPL) % P;
-                } else {
-                    step = kBlock * SPL;
-                    t = sg.n_start + (uint32_t)j0 + tid * SPL;   // the counter itself
-                }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    Quad<OUT_FMT> qo;
-#pragma unroll
-                    for (int k = 0; k < (int)SPL; ++k) {
-                        uint32_t n;
-                        if (P != 0) {
-                            uint32_t e = t + k;
-                            e = (e >= P) ? e - P : e;
-                            n = e + 1u;
-                        } else {
-                            n = t + k;
-                        }
-                        float c, s, a, b, re, im;
-                        corrector<FMA>(sg.ratio, n, c, s);
-                        quad_get<IN_FMT>(qin[u], k, a, b);
-                        mix(a, b, c, s, re, im);
-                        quad_set<OUT_FMT>(qo, k, re, im);
-                    }
-                    store_quad<OUT_FMT>(out, t0 + (uint64_t)(u * kBlock + tid) * SPL, qo);
-                    t += step;
-                    if (P != 0) t = (t >= P) ? t - P : t;
+                for (int i = 0; i < S / 2; ++i) {
+                    u32x4 o;
+                    o[0] = __float_as_uint(re[2 * i]);     o[1] = __float_as_uint(im[2 * i]);
+                    o[2] = __float_as_uint(re[2 * i + 1]); o[3] = __float_as_uint(im[2 * i + 1]);
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(op) + i);
                 }
-            }
-        } else {
-            // ---- ragged tile: stream tail, or a tile that straddles stretches
-            for (uint32_t o = tid; o < TILE; o += kBlock) {
-                const uint64_t g = t0 + o;
-                if (g >= n_samples) break;
-                uint32_t s2 = si;
-                while (s2 + 1 < n_segs && segs[s2].first + segs[s2].count <= g) ++s2;
-                const DevSeg sx = segs[s2];
-                float c, s, a, b, re, im;
-                corrector<FMA>(sx.ratio, counter_at(sx, g - sx.first), c, s);
-                load_one<IN_FMT>(in, g, a, b);
-                mix(a, b, c, s, re, im);
-                store_one<OUT_FMT>(out, g, re, im);
             }
         }
+    } else {
+        // ragged ranges [r0, A) and [B, r1): 4 samples per lane, evaluated one by one
+        const uint64_t head = ra.A - ra.r0;
+        const uint64_t total = head + (ra.r1 - ra.B);
+        const uint64_t e0 = (uint64_t)(b - n_main) * (kRowsLanes * 4);
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t idx = e0 + (uint64_t)k * kRowsLanes + lane;
+            if (idx >= total) break;
+            const uint64_t g = idx < head ? ra.r0 + idx : ra.B + (idx - head);
+            one_sample<IN_FMT, OUT_FMT, FMA>(in, out, segs, ra.n_segs, ra.seg_lo, g);
+        }
+    }
+}
+
+// ---- tile kernel: any mixture of stretches; workgroup b handles tile tile_lo + b and exits
+template <int IN_FMT, int OUT_FMT, bool FMA, int BLOCK, int V>
+__global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__ in,
+                                                     uint8_t *__restrict__ out,
+                                                     const DevSeg *__restrict__ segs,
+                                                     uint32_t n_segs,
+                                                     const uint32_t *__restrict__ hint,
+                                                     const float2 *__restrict__ lut_pool,
+                                                     TileArgs ta)
+{
+    constexpr uint32_t SPL = kSamplesPerLane;
+    constexpr uint32_t TILE = BLOCK * SPL * V;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t tile = ta.tile_lo + blockIdx.x;
+    const uint64_t t0 = tile * TILE;
+    const bool in_mask = t0 >= ta.m0 && t0 + TILE <= ta.m1;
+
+    // request this lane's input right away; nothing below is needed for the addresses
+    Quad<IN_FMT> qin[V];
+    if (in_mask) {
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            qin[v] = load_quad<IN_FMT>(in, t0 + (uint64_t)(v * BLOCK + tid) * SPL);
+    }
+
+    // stretch holding the first produced sample (uniform: scalar loads)
+    const uint64_t gs = t0 > ta.m0 ? t0 : ta.m0;
+    uint32_t si = hint[gs >> kHintShift];
+    while (si + 1 < n_segs && segs[si].first + segs[si].count <= gs) ++si;
+    const DevSeg sg = segs[si];
+    const bool whole = in_mask && (t0 >= sg.first) && (t0 + TILE <= sg.first + sg.count);
+
+    if (whole && sg.lut_len != 0 && !(sg.flags & kSegRows)) {
+        // ---- tabulated correctors: phase of t0 within the period, then straight indexing
+        const uint32_t P = sg.period;
+        // (c0 + t0) mod P with t0 = tile * TILE, all in 32 bits: P <= kLutMaxEntries = 2^13
+        uint32_t ph = sg.c0 + (((uint32_t)tile % P) * sg.tmod) % P;   // tile < 2^32 (checked on the host)
+        ph = (ph >= P) ? ph - P : ph;
+        const float2 *tab = lut_pool + sg.lut_off + ph;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const uint32_t e = (uint32_t)(v * BLOCK + tid) * SPL;
+            float2 cs[SPL];
+#pragma unroll
+            for (int k = 0; k < (int)SPL; ++k) cs[k] = tab[e + k];
+            Quad<OUT_FMT> qo;
+#pragma unroll
+            for (int k = 0; k < (int)SPL; ++k) {
+                float a, b, re, im;
+                quad_get<IN_FMT>(qin[v], k, a, b);
+                mix(a, b, cs[k].x, cs[k].y, re, im);
+                quad_set<OUT_FMT>(qo, k, re, im);
+            }
+            store_quad<OUT_FMT>(out, t0 + (uint64_t)(v * BLOCK + tid) * SPL, qo);
+        }
+    } else if (whole && (sg.period == 0 || sg.period >= 4)) {
+        // ---- sincos per sample: periodic with period >= 4, or linear
+        const uint32_t P = sg.period;
+        const uint64_t j0 = t0 - sg.first;
+        uint32_t base;   // periodic: phase of t0 in [0, P); linear: the counter itself
+        if (P != 0) base = (uint32_t)(((uint64_t)(sg.n_start - 1u) + j0) % P);
+        else        base = sg.n_start + (uint32_t)j0;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            uint32_t t = base + (uint32_t)(v * BLOCK + tid) * SPL;
+            if (P != 0) t %= P;
+            Quad<OUT_FMT> qo;
+#pragma unroll
+            for (int k = 0; k < (int)SPL; ++k) {
+                uint32_t n;
+                if (P != 0) {
+                    uint32_t e = t + k;
+                    e = (e >= P) ? e - P : e;
+                    n = e + 1u;
+                } else {
+                    n = t + k;
+                }
+                float c, s, a, b, re, im;
+                corrector<FMA>(sg.ratio, n, c, s);
+                quad_get<IN_FMT>(qin[v], k, a, b);
+                mix(a, b, c, s, re, im);
+                quad_set<OUT_FMT>(qo, k, re, im);
+            }
+            store_quad<OUT_FMT>(out, t0 + (uint64_t)(v * BLOCK + tid) * SPL, qo);
+        }
+    } else {
+        // ---- ragged tile: mask edge, stream tail, or a tile that straddles stretches
+        for (uint32_t o = tid; o < TILE; o += BLOCK) {
+            const uint64_t g = t0 + o;
+            if (g < ta.m0) continue;
+            if (g >= ta.m1) break;
+            one_sample<IN_FMT, OUT_FMT, FMA>(in, out, segs, n_segs, si, g);
+        }
+    }
+}
+
+// plan-time: entry e of a table = corrector(((n_first - 1 + e) mod period) + 1)
+template <bool FMA>
+__global__ __launch_bounds__(256) void build_lut_kernel(float2 *__restrict__ tab, uint32_t period,
+                                                        uint32_t n_first, uint32_t n_entries, float ratio)
+{
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n_entries; e += gridDim.x * 256u) {
+        float c, s;
+        const uint32_t n = (uint32_t)(((uint64_t)(n_first - 1u) + e) % period) + 1u;
+        corrector<FMA>(ratio, n, c, s);
+        tab[e] = make_float2(c, s);
     }
 }
 
 // ------------------------------------------------------- auxiliary kernels
 
-// calibration: the same 16-byte non-temporal, block-cyclic stream with no math
+constexpr int kBlock = 256;
+
+// calibration: the same one-shot 16-byte non-temporal stream with no math
 __global__ __launch_bounds__(kBlock) void copy_kernel(const u32x4 *__restrict__ in,
                                                       u32x4 *__restrict__ out, uint64_t n_vec)
 {
-    constexpr int U = 4;
-    const uint64_t tile = (uint64_t)kBlock * U;
-    for (uint64_t t0 = (uint64_t)blockIdx.x * tile; t0 < n_vec; t0 += (uint64_t)gridDim.x * tile) {
-        u32x4 v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint64_t i = t0 + (uint64_t)u * kBlock + threadIdx.x;
-            if (i < n_vec) v[u] = __builtin_nontemporal_load(in + i);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint64_t i = t0 + (uint64_t)u * kBlock + threadIdx.x;
-            if (i < n_vec) __builtin_nontemporal_store(v[u], out + i);
-        }
-    }
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_vec) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
 }
 
 // dsp.rs:85-99 on its own (the fused kernel never materialises this)
@@ -318,39 +416,87 @@ __global__ __launch_bounds__(kBlock) void ccexpf_imag_kernel(float2 *__restrict_
 
 // ------------------------------------------------------------ launch wrappers
 
-template <int IN_FMT, int OUT_FMT, bool FMA>
-static int launch_u(const void *d_in, void *d_out, const DevSeg *d_segs, uint32_t n_segs,
-                    uint64_t n_samples, const LaunchGeom &g, hipStream_t st)
+#define DPX_DISPATCH_FMT(FN, ...)                                                                           \
+    do {                                                                                                    \
+        if (in_fmt == DPX_FMT_I16 && out_fmt == DPX_FMT_I16) return FN<DPX_FMT_I16, DPX_FMT_I16>(__VA_ARGS__); \
+        if (in_fmt == DPX_FMT_I16 && out_fmt == DPX_FMT_F32) return FN<DPX_FMT_I16, DPX_FMT_F32>(__VA_ARGS__); \
+        if (in_fmt == DPX_FMT_F32 && out_fmt == DPX_FMT_I16) return FN<DPX_FMT_F32, DPX_FMT_I16>(__VA_ARGS__); \
+        if (in_fmt == DPX_FMT_F32 && out_fmt == DPX_FMT_F32) return FN<DPX_FMT_F32, DPX_FMT_F32>(__VA_ARGS__); \
+        return DPX_ERR_ARG;                                                                                 \
+    } while (0)
+
+template <int IN_FMT, int OUT_FMT>
+static int tiles_t(const void *d_in, void *d_out, const DevSeg *d_segs, uint32_t n_segs,
+                   const uint32_t *d_hint, const void *d_lut, const TileArgs &t, bool fma,
+                   const LaunchGeom &g, hipStream_t st)
 {
     const uint8_t *in = static_cast<const uint8_t *>(d_in);
     uint8_t *out = static_cast<uint8_t *>(d_out);
-    switch (g.unroll) {
-    case 1: shift_kernel<IN_FMT, OUT_FMT, FMA, 1><<<g.grid, kBlock, g.lds_bytes, st>>>(in, out, d_segs, n_segs, n_samples); break;
-    case 2: shift_kernel<IN_FMT, OUT_FMT, FMA, 2><<<g.grid, kBlock, g.lds_bytes, st>>>(in, out, d_segs, n_segs, n_samples); break;
-    case 4: shift_kernel<IN_FMT, OUT_FMT, FMA, 4><<<g.grid, kBlock, g.lds_bytes, st>>>(in, out, d_segs, n_segs, n_samples); break;
-    case 8: shift_kernel<IN_FMT, OUT_FMT, FMA, 8><<<g.grid, kBlock, g.lds_bytes, st>>>(in, out, d_segs, n_segs, n_samples); break;
-    default: return DPX_ERR_ARG;
+    const float2 *lut = static_cast<const float2 *>(d_lut);
+    if (t.n_tiles == 0) return DPX_OK;
+    if (t.n_tiles > 0x7fffffffull) return DPX_ERR_ARG;
+    const dim3 grid((uint32_t)t.n_tiles);
+#define DPX_CASE(B, Vv)                                                                                      \
+    if (g.block == B && g.vecs == Vv) {                                                                      \
+        if (fma) tile_kernel<IN_FMT, OUT_FMT, true, B, Vv><<<grid, B, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t);  \
+        else     tile_kernel<IN_FMT, OUT_FMT, false, B, Vv><<<grid, B, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t); \
+        return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                       \
     }
-    return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;
-}
-
-template <bool FMA>
-static int launch_f(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,
-                    uint32_t n_segs, uint64_t n_samples, const LaunchGeom &g, hipStream_t st)
-{
-    if (in_fmt == DPX_FMT_I16 && out_fmt == DPX_FMT_I16) return launch_u<DPX_FMT_I16, DPX_FMT_I16, FMA>(d_in, d_out, d_segs, n_segs, n_samples, g, st);
-    if (in_fmt == DPX_FMT_I16 && out_fmt == DPX_FMT_F32) return launch_u<DPX_FMT_I16, DPX_FMT_F32, FMA>(d_in, d_out, d_segs, n_segs, n_samples, g, st);
-    if (in_fmt == DPX_FMT_F32 && out_fmt == DPX_FMT_I16) return launch_u<DPX_FMT_F32, DPX_FMT_I16, FMA>(d_in, d_out, d_segs, n_segs, n_samples, g, st);
-    if (in_fmt == DPX_FMT_F32 && out_fmt == DPX_FMT_F32) return launch_u<DPX_FMT_F32, DPX_FMT_F32, FMA>(d_in, d_out, d_segs, n_segs, n_samples, g, st);
+    DPX_CASE(128, 1) DPX_CASE(128, 2) DPX_CASE(256, 1) DPX_CASE(256, 2)
+#undef DPX_CASE
     return DPX_ERR_ARG;
 }
 
-int launch_shift(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,
-                 uint32_t n_segs, uint64_t n_samples, bool fma, const LaunchGeom &g, void *stream)
+int launch_tiles(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,
+                 uint32_t n_segs, const uint32_t *d_hint, const void *d_lut, const TileArgs &t,
+                 bool fma, const LaunchGeom &g, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    return fma ? launch_f<true>(d_in, in_fmt, d_out, out_fmt, d_segs, n_segs, n_samples, g, st)
-               : launch_f<false>(d_in, in_fmt, d_out, out_fmt, d_segs, n_segs, n_samples, g, st);
+    DPX_DISPATCH_FMT(tiles_t, d_in, d_out, d_segs, n_segs, d_hint, d_lut, t, fma, g, st);
+}
+
+template <int IN_FMT, int OUT_FMT>
+static int rows_t(const void *d_in, void *d_out, const DevSeg *d_segs, const void *d_lut,
+                  const RowsArgs &r, bool fma, hipStream_t st)
+{
+    const uint8_t *in = static_cast<const uint8_t *>(d_in);
+    uint8_t *out = static_cast<uint8_t *>(d_out);
+    const float2 *lut = static_cast<const float2 *>(d_lut);
+    constexpr uint32_t S = RowVec<IN_FMT>::S;
+    const uint32_t cols = (r.L + kRowsLanes * S - 1) / (kRowsLanes * S);
+    const uint64_t n_main = r.n_rg * cols;
+    const uint64_t ragged = (r.A - r.r0) + (r.r1 - r.B);
+    const uint64_t n_extra = (ragged + kRowsLanes * 4 - 1) / (kRowsLanes * 4);
+    if (n_main + n_extra == 0) return DPX_OK;
+    if (n_main + n_extra > 0x7fffffffull) return DPX_ERR_ARG;
+    // exact b / cols for b < 2^31: M = ceil(2^(31+s) / cols), s = ceil(log2 cols)
+    uint32_t s = 0;
+    while ((1u << s) < cols) ++s;
+    const uint32_t sh = 31 + s;
+    const uint64_t M = ((1ull << sh) + cols - 1) / cols;
+    const dim3 grid((uint32_t)(n_main + n_extra));
+    const float2 *tab = lut + r.tab_off;
+    if (fma) rows_kernel<IN_FMT, OUT_FMT, true><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_main, d_segs, r);
+    else     rows_kernel<IN_FMT, OUT_FMT, false><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_main, d_segs, r);
+    return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;
+}
+
+int launch_rows(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,
+                const void *d_lut, const RowsArgs &r, bool fma, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DPX_DISPATCH_FMT(rows_t, d_in, d_out, d_segs, d_lut, r, fma, st);
+}
+
+int launch_build_lut(void *d_lut_entries, uint32_t period, uint32_t n_first, uint32_t n_entries,
+                     float ratio, bool fma, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint32_t grid = (n_entries + 255u) / 256u;
+    float2 *tab = static_cast<float2 *>(d_lut_entries);
+    if (fma) build_lut_kernel<true><<<grid, 256, 0, st>>>(tab, period, n_first, n_entries, ratio);
+    else     build_lut_kernel<false><<<grid, 256, 0, st>>>(tab, period, n_first, n_entries, ratio);
+    return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;
 }
 
 static int aux_grid(uint64_t n)
@@ -359,10 +505,14 @@ static int aux_grid(uint64_t n)
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
-int launch_copy(const void *d_in, void *d_out, uint64_t n_bytes, int grid, void *stream)
+int launch_copy(const void *d_in, void *d_out, uint64_t n_bytes, void *stream)
 {
-    copy_kernel<<<grid, kBlock, 0, static_cast<hipStream_t>(stream)>>>(
-        static_cast<const u32x4 *>(d_in), static_cast<u32x4 *>(d_out), n_bytes / 16);
+    const uint64_t n_vec = n_bytes / 16;
+    const uint64_t grid = (n_vec + kBlock - 1) / kBlock;
+    if (grid == 0) return DPX_OK;
+    if (grid > 0x7fffffffull) return DPX_ERR_ARG;
+    copy_kernel<<<(uint32_t)grid, kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const u32x4 *>(d_in), static_cast<u32x4 *>(d_out), n_vec);
     return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;
 }
 

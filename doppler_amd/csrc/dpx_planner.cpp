@@ -4,6 +4,7 @@
 #include "dpx_planner.h"
 
 #include <math.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -48,14 +49,11 @@ bool find_reset(float ratio, uint32_t n_start, uint64_t max_scan, uint32_t *n_re
 
 static uint32_t lut_len_for(uint32_t period, uint64_t count, int variant)
 {
-    // the table length must be >= 4 so that 4 consecutive entries wrap at most once
-    const uint32_t reps = period >= 4 ? 1u : (4u + period - 1u) / period;
-    const uint64_t len = (uint64_t)period * reps;
-    if (period < 4) return (uint32_t)len;           // only the table path handles tiny periods
+    if (period < 4) return period;                 // only the table path handles tiny periods
     if (variant == 1) return 0;
-    if (len > kLutMaxEntries) return 0;
-    if (variant == 2) return (uint32_t)len;
-    return count >= 2 * len ? (uint32_t)len : 0;
+    if (period > kLutMaxEntries) return 0;
+    if (variant == 2) return period;
+    return count >= 2ull * period ? period : 0;    // a table pays once it is reused
 }
 
 static void emit(PlanResult &plan, uint64_t first, uint64_t count, float ratio, uint32_t n_start,
@@ -68,8 +66,11 @@ static void emit(PlanResult &plan, uint64_t first, uint64_t count, float ratio, 
     s.n_start = n_start;
     s.period = period;
     s.lut_len = lut_len;
+    s.lut_off = 0;   // assigned by finalize()
+    s.c0 = 0;
+    s.tmod = 0;
+    s.flags = 0;
     plan.segs.push_back(s);
-    plan.max_lut_len = std::max(plan.max_lut_len, lut_len);
 }
 
 void plan_append(PlanResult &plan, float ratio, uint64_t count, uint32_t &samplenum, int variant)
@@ -111,6 +112,220 @@ void plan_append(PlanResult &plan, float ratio, uint64_t count, uint32_t &sample
     plan.n_samples = pos;
     samplenum = n;
     plan.final_samplenum = n;
+}
+
+uint32_t counter_at(const DevSeg &s, uint64_t j)
+{
+    if (s.period == 0) return s.n_start + (uint32_t)j;
+    return (uint32_t)(((uint64_t)(s.n_start - 1u) + j) % s.period) + 1u;
+}
+
+namespace {
+
+constexpr uint64_t kRowsMinSamples = 1u << 16;   // below this a stretch stays on the tile kernel
+constexpr uint64_t kAbsorbMax = 4096;            // neighbouring crumbs a rows launch may evaluate itself
+
+// Row length for period P: a multiple of lcm(P, 4) not above kLutMaxEntries.  Preference order:
+// (1) a multiple of 32 samples, so that every row starts on a 128-byte line (a wavefront's
+// 1 KiB piece then never shares a line with a wavefront on another XCD — measured: a 16-byte
+// skew of the matrix origin alone costs ~20 %); (2) fewest idle lanes in the last 256-sample
+// column slice.  Returns 0 if no multiple fits.
+uint32_t pick_row_length(uint32_t P)
+{
+    uint64_t g = P, h = 4;
+    while (h) { const uint64_t t = g % h; g = h; h = t; }
+    const uint64_t base = (uint64_t)P / g * 4;
+    if (base > kLutMaxEntries) return 0;
+    uint32_t best = 0;
+    double best_score = -1.0;
+    for (uint64_t L = base; L <= kLutMaxEntries; L += base) {
+        const double eff = (double)L / (256.0 * (double)((L + 255) / 256));
+        const double score = eff + (L % 32 == 0 ? 1.0 : 0.0);
+        if (score > best_score + 1e-9) { best_score = score; best = (uint32_t)L; }
+    }
+    return best;
+}
+
+struct Interval { uint64_t lo, hi; };
+
+}  // namespace
+
+void finalize(PlanResult &plan, uint32_t tile, bool use_rows)
+{
+    plan.tile = tile;
+    plan.tables.clear();
+    plan.launches.clear();
+    const size_t ns = plan.segs.size();
+    uint64_t pool = 0;
+
+    // ---- which stretches go to the rows kernel
+    std::vector<Interval> covered;
+    for (size_t i = 0; i < ns; ++i) {
+        DevSeg &s = plan.segs[i];
+        s.flags = 0;
+        if (!use_rows || s.lut_len == 0 || s.count < kRowsMinSamples) continue;
+        const uint32_t L = pick_row_length(s.period);
+        if (L == 0) continue;
+        const uint64_t end = s.first + s.count;
+        // matrix origin on a 256-sample boundary: 1 KiB of i16 / 2 KiB of f32 per wavefront, aligned
+        const uint64_t A = (s.first + 255) & ~255ull;
+        if (A >= end) continue;
+        const uint64_t n_rg = (end - A) / ((uint64_t)kRowsR * L);
+        if (n_rg < 16) continue;
+        s.flags |= kSegRows | kSegOwnsTable;
+        Launch ln;
+        ln.kind = 0;
+        ln.rows.A = A;
+        ln.rows.B = A + n_rg * kRowsR * L;
+        ln.rows.n_rg = n_rg;
+        ln.rows.L = L;
+        ln.rows.r0 = s.first;
+        ln.rows.r1 = end;
+        ln.rows.seg_lo = (uint32_t)i;
+        ln.rows.n_segs = (uint32_t)ns;
+        // table: L entries, origin = sample A
+        s.lut_off = (uint32_t)pool;
+        ln.rows.tab_off = s.lut_off;
+        plan.tables.push_back({pool, s.period, counter_at(s, A - s.first), L, s.ratio});
+        pool += ((uint64_t)L + 3) & ~3ull;
+        plan.launches.push_back(ln);
+    }
+    // a rows launch also evaluates small neighbouring crumbs (e.g. the one-sample lead-in of a
+    // stream that starts at counter 0), so that such a plan is a single launch.  Launches are in
+    // stretch order, so "not below the previous launch's r1" keeps the ranges disjoint.
+    uint64_t covered_hi = 0;
+    for (Launch &ln : plan.launches) {
+        uint32_t lo = ln.rows.seg_lo;
+        while (lo > 0) {
+            const DevSeg &p = plan.segs[lo - 1];
+            if ((p.flags & kSegRows) || p.first < covered_hi || ln.rows.A - p.first > kAbsorbMax) break;
+            --lo;
+        }
+        ln.rows.seg_lo = lo;
+        ln.rows.r0 = plan.segs[lo].first;
+        // seg_lo was the stretch itself before the walk; the following stretches start right after it
+        uint32_t hi = lo;
+        while (hi < ns && plan.segs[hi].first < ln.rows.r1) ++hi;
+        while (hi < ns) {
+            const DevSeg &q = plan.segs[hi];
+            if ((q.flags & kSegRows) || q.first + q.count - ln.rows.B > kAbsorbMax) break;
+            ln.rows.r1 = q.first + q.count;
+            ++hi;
+        }
+        covered_hi = ln.rows.r1;
+        covered.push_back({ln.rows.r0, ln.rows.r1});
+    }
+
+    // ---- tables of the tabulated stretches that stay on the tile kernel
+    const DevSeg *prev = nullptr;   // same (ratio, period) shares a table
+    for (DevSeg &s : plan.segs) {
+        if (s.lut_len == 0 || (s.flags & kSegRows)) continue;
+        const uint32_t P = s.period;
+        s.c0 = (uint32_t)(((uint64_t)((s.n_start - 1u) % P) + P - (s.first % P)) % P);
+        s.tmod = tile % P;
+        if (prev && prev->period == P && memcmp(&prev->ratio, &s.ratio, sizeof(float)) == 0) {
+            s.lut_off = prev->lut_off;
+            prev = &s;
+            continue;
+        }
+        s.flags |= kSegOwnsTable;
+        prev = &s;
+        s.lut_off = (uint32_t)pool;
+        plan.tables.push_back({pool, P, 1u, P + tile, s.ratio});
+        pool += ((uint64_t)P + tile + 3) & ~3ull;
+    }
+    plan.lut_entries = pool;
+
+    // ---- everything no rows launch covers goes to tile-kernel launches
+    std::sort(covered.begin(), covered.end(), [](const Interval &a, const Interval &b) { return a.lo < b.lo; });
+    uint64_t pos = 0;
+    auto add_tiles = [&](uint64_t lo, uint64_t hi) {
+        if (lo >= hi) return;
+        Launch ln;
+        ln.kind = 1;
+        ln.tiles.m0 = lo;
+        ln.tiles.m1 = hi;
+        ln.tiles.tile_lo = lo / tile;
+        ln.tiles.n_tiles = (hi + tile - 1) / tile - ln.tiles.tile_lo;
+        plan.launches.push_back(ln);
+    };
+    for (const Interval &c : covered) {
+        add_tiles(pos, c.lo);
+        pos = std::max(pos, c.hi);
+    }
+    add_tiles(pos, plan.n_samples);
+
+    // ---- one hint per 2^kHintShift samples: the stretch holding the first sample of that span
+    const uint64_t n_hint = (plan.n_samples >> kHintShift) + 1;
+    plan.hint.assign(n_hint, 0);
+    uint32_t si = 0;
+    for (uint64_t h = 0; h < n_hint; ++h) {
+        const uint64_t g = h << kHintShift;
+        while (si + 1 < ns && plan.segs[si].first + plan.segs[si].count <= g) ++si;
+        plan.hint[h] = si;
+    }
+}
+
+void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
+{
+    const uint32_t ns = (uint32_t)plan.segs.size();
+    auto put = [&](uint64_t g, uint32_t n) {
+        n_out[g] = n;
+        if (writes[g] < 255) ++writes[g];
+    };
+    auto generic = [&](uint32_t si, uint64_t g) {     // one_sample()
+        while (si + 1 < ns && plan.segs[si].first + plan.segs[si].count <= g) ++si;
+        put(g, counter_at(plan.segs[si], g - plan.segs[si].first));
+    };
+    for (const Launch &ln : plan.launches) {
+        if (ln.kind == 0) {
+            const RowsArgs &r = ln.rows;
+            const DevSeg &s = plan.segs[0];
+            (void)s;
+            // the table this launch reads: entry e -> ((n_first - 1 + e) mod P) + 1
+            const TableBuild *tb = nullptr;
+            for (const TableBuild &t : plan.tables) if (t.off == r.tab_off) tb = &t;
+            for (uint64_t rg = 0; rg < r.n_rg; ++rg)
+                for (int row = 0; row < kRowsR; ++row)
+                    for (uint32_t cs = 0; cs < r.L; ++cs) {
+                        const uint64_t g = r.A + (rg * kRowsR + row) * (uint64_t)r.L + cs;
+                        put(g, (uint32_t)(((uint64_t)(tb->n_first - 1u) + cs) % tb->period) + 1u);
+                    }
+            for (uint64_t g = r.r0; g < r.A; ++g) generic(r.seg_lo, g);
+            for (uint64_t g = r.B; g < r.r1; ++g) generic(r.seg_lo, g);
+        } else {
+            const TileArgs &t = ln.tiles;
+            for (uint64_t tile = t.tile_lo; tile < t.tile_lo + t.n_tiles; ++tile) {
+                const uint64_t t0 = tile * plan.tile;
+                const bool in_mask = t0 >= t.m0 && t0 + plan.tile <= t.m1;
+                const uint64_t gs = t0 > t.m0 ? t0 : t.m0;
+                uint32_t si = plan.hint[gs >> kHintShift];
+                while (si + 1 < ns && plan.segs[si].first + plan.segs[si].count <= gs) ++si;
+                const DevSeg &sg = plan.segs[si];
+                const bool whole = in_mask && t0 >= sg.first && t0 + plan.tile <= sg.first + sg.count;
+                if (whole && sg.lut_len != 0 && !(sg.flags & kSegRows)) {
+                    const uint32_t P = sg.period;
+                    uint32_t ph = sg.c0 + (((uint32_t)tile % P) * sg.tmod) % P;
+                    ph = ph >= P ? ph - P : ph;
+                    for (uint32_t e = 0; e < plan.tile; ++e) put(t0 + e, ((ph + e) % P) + 1u);
+                } else if (whole && (sg.period == 0 || sg.period >= 4)) {
+                    const uint32_t P = sg.period;
+                    const uint64_t j0 = t0 - sg.first;
+                    for (uint32_t e = 0; e < plan.tile; ++e) {
+                        if (P) put(t0 + e, (uint32_t)((((uint64_t)(sg.n_start - 1u) + j0) % P + e) % P) + 1u);
+                        else put(t0 + e, sg.n_start + (uint32_t)j0 + e);
+                    }
+                } else {
+                    for (uint32_t e = 0; e < plan.tile; ++e) {
+                        const uint64_t g = t0 + e;
+                        if (g < t.m0) continue;
+                        if (g >= t.m1) break;
+                        generic(si, g);
+                    }
+                }
+            }
+        }
+    }
 }
 
 }  // namespace dpx

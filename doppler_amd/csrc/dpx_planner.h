@@ -24,14 +24,44 @@ bool is_reset(float ratio, uint32_t n);
 // first n in [n_start, n_start + max_scan) (not past 2^32-1) with is_reset; false if none
 bool find_reset(float ratio, uint32_t n_start, uint64_t max_scan, uint32_t *n_reset);
 
+struct TableBuild {     // one corrector table to fill at plan time
+    uint64_t off;       // pool entry index
+    uint32_t period, n_first, n_entries;
+    float ratio;
+};
+
+struct Launch {
+    int kind;           // 0 = rows kernel, 1 = tile kernel
+    RowsArgs rows;
+    TileArgs tiles;
+};
+
 struct PlanResult {
     std::vector<DevSeg> segs;   // consecutive, covering [0, n_samples)
     uint64_t n_samples = 0;
     uint32_t final_samplenum = 0;
-    uint32_t max_lut_len = 0;
+    // filled by finalize():
+    uint64_t lut_entries = 0;        // size of the corrector-table pool, in (cos, sin) entries
+    uint32_t tile = 0;               // tile-kernel samples per workgroup the tables were laid out for
+    std::vector<uint32_t> hint;      // stretch index per 2^kHintShift samples
+    std::vector<TableBuild> tables;
+    std::vector<Launch> launches;
 };
 
-// variant: 0 auto, 1 never use the LDS table (except period < 4), 2 table whenever it fits
+// variant: 0 auto, 1 sincos per sample wherever the period allows (>= 4), 2 tables whenever they fit
 void plan_append(PlanResult &plan, float ratio, uint64_t count, uint32_t &samplenum, int variant);
+
+// after the last plan_append: choose the kernel for every stretch, lay out the
+// corrector tables, build the hint table and the launch list.
+// use_rows = false keeps everything on the tile kernel (measurement A/B).
+void finalize(PlanResult &plan, uint32_t tile, bool use_rows);
+
+// Host mirror of the kernels' index arithmetic (no arithmetic on samples): for every
+// sample of a finalized plan, the counter value the launches would use, and how many
+// times the sample is written.  n_out / writes hold plan.n_samples entries.
+void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes);
+
+// counter value at sample j of a stretch (host mirror of the kernels' counter_at)
+uint32_t counter_at(const DevSeg &s, uint64_t j);
 
 }  // namespace dpx

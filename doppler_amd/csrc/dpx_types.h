@@ -8,8 +8,15 @@ namespace dpx {
 // single closed form.  For sample j = g - first of the stretch:
 //   period == 0 ("linear"):   n = n_start + j            (no reset inside)
 //   period  > 0 ("periodic"): n = ((n_start - 1 + j) mod period) + 1
-// lut_len > 0 asks the kernel to keep the correctors of one period in LDS
-// (lut_len is a multiple of period, >= 4); 0 means evaluate sincos per sample.
+// lut_len > 0 ("tabulated"): the correctors of one period (lut_len == period)
+// are precomputed.  How the table is laid out depends on which kernel serves
+// the stretch (flags):
+//   kSegRows:  rows kernel; table of RowsArgs::L entries starting at the phase of
+//              sample RowsArgs::A (no phase arithmetic in the kernel at all);
+//   otherwise: tile kernel; table of period + tile entries, entry e holding
+//              corrector((e mod period) + 1), indexed from the tile's phase
+//              (c0 + tile_index * tmod) mod period.
+// lut_len == 0: sincos is evaluated per sample.
 struct DevSeg {
     uint64_t first;     // global sample index of the first sample
     uint64_t count;     // samples in this stretch (> 0)
@@ -17,23 +24,69 @@ struct DevSeg {
     uint32_t n_start;   // counter value used by the first sample
     uint32_t period;
     uint32_t lut_len;
+    uint32_t lut_off;   // table-pool entry index of this stretch's table
+    uint32_t c0;        // (n_start - 1 - first) mod period: phase of global sample 0
+    uint32_t tmod;      // tile mod period
+    uint32_t flags;
 };
-static_assert(sizeof(DevSeg) == 32, "DevSeg is read with scalar loads; keep it 32 bytes");
+static_assert(sizeof(DevSeg) == 48, "DevSeg is read with scalar loads");
 
+constexpr uint32_t kSegOwnsTable = 1u;   // this stretch's table must be built (not shared)
+constexpr uint32_t kSegRows = 2u;        // served by a rows-kernel launch
+
+// the first 32 bytes, as exposed through the C ABI (dpx_stretch)
+struct StretchView {
+    uint64_t first, count;
+    float ratio;
+    uint32_t n_start, period, lut_len;
+};
+
+constexpr int kSamplesPerLane = 4;          // tile kernel: one 16-byte i16 vector = 4 IQ samples
+constexpr uint32_t kLutMaxEntries = 8192;   // longest table (64 KiB: stays L2-resident)
+constexpr int kHintShift = 16;              // one stretch hint per 65536 samples
+constexpr int kRowsLanes = 64;              // rows kernel: one wavefront per workgroup
+constexpr int kRowsR = 2;                   // rows per workgroup (share one set of correctors)
+
+// tile-kernel geometry
 struct LaunchGeom {
-    int grid;           // workgroups
-    int unroll;         // 16-byte vectors in flight per lane (template instance)
-    uint32_t lds_bytes; // dynamic LDS for the corrector table
+    int block;    // 128 or 256 lanes per workgroup
+    int vecs;     // 4-sample groups per lane: 1, 2 or 4
+    uint32_t tile() const { return (uint32_t)block * kSamplesPerLane * (uint32_t)vecs; }
 };
 
-constexpr int kBlock = 256;          // 4 wavefronts of 64
-constexpr int kSamplesPerLane = 4;   // one 16-byte i16 vector = 4 IQ samples
-constexpr uint32_t kLutMaxEntries = 4096;   // 32 KiB of LDS per workgroup
+// One rows-kernel launch: a tabulated periodic stretch processed as a matrix whose
+// rows are L samples long (L a multiple of the period and of 4), so that a column
+// always sees the same corrector.  A workgroup (one wavefront) takes kRowsR
+// consecutive rows x 64 lanes x S samples; column slices of one row group are
+// consecutive workgroups, so the grid sweeps HBM contiguously.
+// Workgroups past n_rg * cols evaluate the ragged ranges [r0, A) and [B, r1)
+// sample by sample (generic stretch lookup, sincos per sample).
+struct RowsArgs {
+    uint64_t A;          // first sample of the matrix (multiple of 256)
+    uint64_t B;          // one past its last sample: A + n_rg * kRowsR * L
+    uint64_t r0, r1;     // ragged ranges [r0, A) and [B, r1) handled by the extra workgroups
+    uint64_t n_rg;       // row groups
+    uint32_t L;          // row length in samples
+    uint32_t tab_off;    // table-pool entry index of the L-entry table (origin: sample A)
+    uint32_t seg_lo;     // index of the stretch holding r0
+    uint32_t n_segs;
+};
+
+struct TileArgs {
+    uint64_t tile_lo;    // first tile of this launch (global tiling from sample 0)
+    uint64_t n_tiles;
+    uint64_t m0, m1;     // only samples in [m0, m1) are produced
+};
 
 // launch wrappers implemented in dpx_kernels.hip (all asynchronous on `stream`)
-int launch_shift(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,
-                 uint32_t n_segs, uint64_t n_samples, bool fma, const LaunchGeom &g, void *stream);
-int launch_copy(const void *d_in, void *d_out, uint64_t n_bytes, int grid, void *stream);
+int launch_tiles(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,
+                 uint32_t n_segs, const uint32_t *d_hint, const void *d_lut, const TileArgs &t,
+                 bool fma, const LaunchGeom &g, void *stream);
+int launch_rows(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,
+                const void *d_lut, const RowsArgs &r, bool fma, void *stream);
+int launch_build_lut(void *d_lut_entries, uint32_t period, uint32_t n_first, uint32_t n_entries,
+                     float ratio, bool fma, void *stream);
+int launch_copy(const void *d_in, void *d_out, uint64_t n_bytes, void *stream);
 int launch_unpack_i16(const void *d_in, void *d_out, uint64_t n_samples, void *stream);
 int launch_pack_i16(const void *d_in, void *d_out, uint64_t n_samples, void *stream);
 int launch_ccexpf_imag(void *d_z, uint64_t n, bool fma, void *stream);

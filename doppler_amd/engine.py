@@ -65,8 +65,10 @@ class Context:
     def handle(self):
         return self._h
 
-    def set_tuning(self, blocks_per_cu=0, unroll=0, variant=0):
-        check(self._lib.dpx_set_tuning(self._h, blocks_per_cu, unroll, variant))
+    def set_tuning(self, block=0, vecs=0, variant=3):
+        """block: lanes per workgroup (128/256); vecs: 4-sample groups per lane (1/2/4);
+        variant: 3 auto, 1 sincos per sample, 2 tabulated correctors. Applies to plans created afterwards."""
+        check(self._lib.dpx_set_tuning(self._h, block, vecs, variant))
 
     def set_libm_contraction(self, fma=True):
         check(self._lib.dpx_set_libm_contraction(self._h, 1 if fma else 0))
@@ -92,6 +94,7 @@ class Context:
         check(self._lib.dpx_synchronize(self._h))
 
     def debug_copy(self, d_in, d_out, nbytes, stream=0):
+        """Calibration: one-shot 16-byte non-temporal copy with the fused kernel's access pattern."""
         check(self._lib.dpx_debug_copy(self._h, C.c_void_p(d_in), C.c_void_p(d_out), nbytes, C.c_void_p(stream)))
 
     # ---- plans
@@ -184,6 +187,24 @@ def plan_describe(segments, samplerate, samplenum=0, variant=0):
     res = [dict(first=s.first, count=s.count, ratio=np.float32(s.ratio), n_start=s.n_start, period=s.period,
                 lut_len=s.lut_len) for s in out[: n_out.value]]
     return res, fin.value
+
+
+def plan_simulate(segments, samplerate, samplenum=0, block=0, vecs=0, variant=3):
+    """Host-only: per-sample counter values the launch list of a plan selects, and per-sample write
+    counts (must all be 1). Returns (counters uint32[n], writes uint8[n]). Needs no GPU."""
+    lib = _lib_handle()
+    segs = list(segments)
+    arr = (_lib.Segment * max(1, len(segs)))()
+    n = 0
+    for i, (cnt, hz) in enumerate(segs):
+        arr[i].n_samples = int(cnt)
+        arr[i].shift_hz = float(hz)
+        n += int(cnt)
+    counters = np.zeros(n, dtype=np.uint32)
+    writes = np.zeros(n, dtype=np.uint8)
+    check(lib.dpx_plan_simulate(arr, len(segs), int(samplerate), int(samplenum), block, vecs, variant,
+                                counters.ctypes.data, writes.ctypes.data, n))
+    return counters, writes
 
 
 def find_reset(shift_hz, samplerate, n_start, max_scan):

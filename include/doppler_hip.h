@@ -128,6 +128,14 @@ int dpx_plan_describe(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
                       uint32_t samplenum0, int variant, dpx_stretch *out, size_t cap,
                       size_t *n_out, uint32_t *final_samplenum);
 
+/* Host-only self-check of a plan's launch list (no device needed): for every sample,
+ * the counter value the kernels' index arithmetic selects (counters[n_samples]) and
+ * how many launches write it (writes[n_samples], must be exactly 1 everywhere).
+ * block / vecs / variant as in dpx_set_tuning (0 = defaults). */
+int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
+                      uint32_t samplenum0, int block, int vecs, int variant,
+                      uint32_t *counters, uint8_t *writes, uint64_t n_samples);
+
 /* ----------------------------------------------- bulk API (device pointers) */
 
 /* constant shift over n_samples starting with counter samplenum0 */
@@ -151,10 +159,15 @@ int dpx_run_device(dpx_plan *plan, const void *d_in, int in_fmt, void *d_out, in
  * Calibration only (profiles/: what the memory system gives a pure stream). */
 int dpx_debug_copy(dpx_ctx *ctx, const void *d_in, void *d_out, size_t n_bytes, void *hip_stream);
 
-/* Kernel-geometry knobs for measurement sweeps (0 keeps the current value).
- * variant: 0 = auto (LDS table when the period fits, else on-the-fly sincos),
- *          1 = force on-the-fly, 2 = force table (fails at run if it cannot). */
-int dpx_set_tuning(dpx_ctx *ctx, int blocks_per_cu, int unroll, int variant);
+/* Measurement knobs (0 keeps the current value); they apply to plans created afterwards.
+ * block / vecs: tile-kernel geometry, lanes per workgroup (128 or 256) and 4-sample groups
+ *          per lane (1 or 2); the rows kernel always runs one wavefront x 2 rows.
+ * variant: 3 = auto: tabulated correctors when the period is <= 8192 samples (rows kernel for
+ *              stretches of >= 65536 samples, tile kernel otherwise), sincos per sample else;
+ *          1 = sincos per sample wherever the period allows it (>= 4);
+ *          2 = tabulate whenever the period fits;
+ *          4 = auto, but keep everything on the tile kernel. */
+int dpx_set_tuning(dpx_ctx *ctx, int block, int vecs, int variant);
 
 /* Which build of glibc's sincosf the correctors reproduce bit-for-bit:
  * fma = 1 (default): the FMA build libm selects on every x86-64 CPU with FMA+AVX2;

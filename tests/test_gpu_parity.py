@@ -140,8 +140,8 @@ def test_const_stream_bulk_vs_oracle(ctx, orc, intype, outtype):
     d_out = ctx.malloc(n * FS[outtype])
     try:
         ctx.h2d(d_in, x)
-        for variant, unroll in [(0, 4), (1, 4), (2, 2), (0, 8), (1, 1)]:
-            ctx.set_tuning(8, unroll, variant if variant else 3)
+        for variant, block, vecs in [(3, 256, 1), (4, 256, 1), (1, 256, 1), (2, 128, 1), (4, 128, 2), (1, 256, 2)]:
+            ctx.set_tuning(block, vecs, variant)
             plan = ctx.plan_const(5000.0, 1024000, n)
             got = np.zeros(n * FS[outtype], dtype=np.uint8)
             ctx.h2d(d_out, got)
@@ -149,9 +149,9 @@ def test_const_stream_bulk_vs_oracle(ctx, orc, intype, outtype):
             ctx.synchronize()
             ctx.d2h(got, d_out)
             assert plan.final_samplenum == sn_w
-            assert_same_bytes(got, want, outtype, "variant=%d unroll=%d" % (variant, unroll))
+            assert_same_bytes(got, want, outtype, "variant=%d block=%d vecs=%d" % (variant, block, vecs))
             plan.close()
     finally:
-        ctx.set_tuning(8, 4, 3)
+        ctx.set_tuning(256, 1, 3)
         ctx.free(d_in)
         ctx.free(d_out)

@@ -1,7 +1,7 @@
 """Measurement sweep for the fused kernel on one MI355X (development tool, not the bench contract).
 
 python tools/sweep.py [--n SAMPLES] [--iters K]
-Prints one line per (format pair, variant, unroll, blocks/CU): average kernel ms (HIP events on the
+Prints one line per (format pair, variant, workgroup geometry): average kernel ms (HIP events on the
 launch stream) and algorithmic GB/s.  Also times the calibration copy kernel.
 """
 import argparse
@@ -40,9 +40,8 @@ def main():
     ap.add_argument("--pairs", default="i16:i16")
     ap.add_argument("--shift", type=float, default=5000.0)
     ap.add_argument("--rate", type=int, default=1024000)
-    ap.add_argument("--variants", default="0,1")
-    ap.add_argument("--unrolls", default="1,2,4,8")
-    ap.add_argument("--bpcs", default="4,8,16")
+    ap.add_argument("--variants", default="3,4,1")
+    ap.add_argument("--geoms", default="128x1,128x2,256x1,256x2")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
@@ -57,22 +56,20 @@ def main():
         out = torch.empty(n * BPS[ot], dtype=torch.uint8, device=dev)
         alg = n * (BPS[it] + BPS[ot])
         if it == ot:
-            for bpc in [int(b) for b in args.bpcs.split(",")]:
-                ctx.set_tuning(bpc, 4, 3)
-                avg, med, mn = time_launches(lambda: ctx.debug_copy(x.data_ptr(), out.data_ptr(), n * BPS[it], stream), args.iters)
-                print(json.dumps({"kernel": "copy", "pair": pair, "bpc": bpc, "ms_avg": round(avg, 4), "ms_min": round(mn, 4),
-                                  "GBps_avg": round(alg / avg / 1e6, 1), "GBps_best": round(alg / mn / 1e6, 1)}), flush=True)
+            avg, med, mn = time_launches(lambda: ctx.debug_copy(x.data_ptr(), out.data_ptr(), n * BPS[it], stream), args.iters)
+            print(json.dumps({"kernel": "copy", "pair": pair, "ms_avg": round(avg, 4), "ms_min": round(mn, 4),
+                              "GBps_avg": round(alg / avg / 1e6, 1), "GBps_best": round(alg / mn / 1e6, 1)}), flush=True)
         for variant in [int(v) for v in args.variants.split(",")]:
-            for unroll in [int(u) for u in args.unrolls.split(",")]:
-                for bpc in [int(b) for b in args.bpcs.split(",")]:
-                    ctx.set_tuning(bpc, unroll, variant if variant else 3)
-                    plan = ctx.plan_const(args.shift, args.rate, n)
-                    avg, med, mn = time_launches(lambda: plan.run(x.data_ptr(), it, out.data_ptr(), ot, stream), args.iters)
-                    print(json.dumps({"kernel": "shift", "pair": pair, "variant": variant, "unroll": unroll, "bpc": bpc,
-                                      "ms_avg": round(avg, 4), "ms_med": round(med, 4), "ms_min": round(mn, 4),
-                                      "GBps_avg": round(alg / avg / 1e6, 1), "GBps_best": round(alg / mn / 1e6, 1),
-                                      "Msps_avg": round(n / avg / 1e3, 0)}), flush=True)
-                    plan.close()
+            for geom in (args.geoms.split(",") if variant != 3 else ["256x1"]):
+                block, vecs = [int(t) for t in geom.split("x")]
+                ctx.set_tuning(block, vecs, variant)
+                plan = ctx.plan_const(args.shift, args.rate, n)
+                avg, med, mn = time_launches(lambda: plan.run(x.data_ptr(), it, out.data_ptr(), ot, stream), args.iters)
+                print(json.dumps({"kernel": "shift", "pair": pair, "variant": variant, "block": block, "vecs": vecs,
+                                  "ms_avg": round(avg, 4), "ms_med": round(med, 4), "ms_min": round(mn, 4),
+                                  "GBps_avg": round(alg / avg / 1e6, 1), "GBps_best": round(alg / mn / 1e6, 1),
+                                  "Msps_avg": round(n / avg / 1e3, 0)}), flush=True)
+                plan.close()
         del x, out
         torch.cuda.empty_cache()
 
