@@ -179,11 +179,15 @@ def shift_block(inbytes, intype, outtype, samplenum, shift_hz, samplerate):
     return out[: cnt.value * _BPS[ot]], bool(r), cnt.value, sn.value
 
 
-def const_stream(inbytes, intype, outtype, shift, samplerate, samplenum=0, threads=1):
-    """`doppler const` (main.rs:102-119) over an in-memory stream. Returns (out_bytes, samplenum)."""
+def const_stream(inbytes, intype, outtype, shift, samplerate, samplenum=0, threads=1, out=None):
+    """`doppler const` (main.rs:102-119) over an in-memory stream. Returns (out_bytes, samplenum).
+    `out`: optional preallocated (and pre-touched) uint8 buffer, for timing runs."""
     b = _bytes(inbytes)
     it, ot = _FMT[intype], _FMT[outtype]
-    out = np.empty(b.size // _BPS[it] * _BPS[ot] + 8, dtype=np.uint8)
+    need = b.size // _BPS[it] * _BPS[ot] + 8
+    if out is None:
+        out = np.empty(need, dtype=np.uint8)
+    assert out.dtype == np.uint8 and out.size >= need and out.flags["C_CONTIGUOUS"]
     if threads > 1:
         assert samplenum == 0
         r = lib.orc_const_stream_mt(b.ctypes.data, b.size, it, ot, shift, samplerate, out.ctypes.data, threads)

@@ -1,49 +1,41 @@
-"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+"""GPU parity tests: the HIP path (always through the C ABI) against the CPU oracle and the committed
+golden vectors, bit for bit.
 
-Tolerances (north_star: f32 within 1 ulp, i16 within +-1 LSB) are met with margin 0:
-every comparison below is exact equality of the output bytes, except that any NaN
-matches any NaN (x86 and CDNA4 propagate different NaN payloads through a*c - b*s).
+Tolerances: north_star allows 1 ulp (f32) / +-1 LSB (i16).  Every comparison below is exact equality of
+the output bytes (tolerance 0), except that any NaN matches any NaN for f32 outputs.
 """
+import os
+
 import numpy as np
 import pytest
 
+from helpers import BPS, assert_same_bytes, load_golden, make_iq, shift_block_cases
+
 pytestmark = pytest.mark.gpu
 
-FS = {"i16": 4, "f32": 8}
+
+def run_bulk(ctx, x, intype, outtype, segments, rate, sn0=0):
+    """Device-resident bulk path: upload, plan, launch, download."""
+    n = sum(c for c, _ in segments)
+    assert x.size == n * BPS[intype]
+    d_in, d_out = ctx.malloc(max(16, x.size)), ctx.malloc(max(16, n * BPS[outtype]))
+    try:
+        ctx.h2d(d_in, x)
+        got = np.full(n * BPS[outtype], 0x5A, dtype=np.uint8)
+        ctx.h2d(d_out, got)
+        plan = ctx.plan_segments(segments, rate, sn0)
+        plan.run(d_in, intype, d_out, outtype)
+        ctx.synchronize()
+        ctx.d2h(got, d_out)
+        fin = plan.final_samplenum
+        plan.close()
+        return got, fin
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_out)
 
 
-def make_iq(fmt, n, seed, full_scale=False):
-    rng = np.random.default_rng(seed)
-    if fmt == "i16":
-        lim = 32767 if full_scale else 23170
-        a = rng.integers(-lim - (1 if full_scale else 0), lim + 1, size=2 * n, dtype=np.int16)
-        return a.view(np.uint8)
-    a = rng.uniform(-1.0, 1.0, size=2 * n).astype(np.float32)
-    return a.view(np.uint8)
-
-
-def assert_same_bytes(got, want, outfmt, what=""):
-    got = np.asarray(got).view(np.uint8).reshape(-1)
-    want = np.asarray(want).view(np.uint8).reshape(-1)
-    assert got.size == want.size, "%s: %d bytes vs %d" % (what, got.size, want.size)
-    if outfmt == "f32":
-        g, w = got.view(np.uint32), want.view(np.uint32)
-        bad = g != w
-        if bad.any():
-            gf, wf = got.view(np.float32), want.view(np.float32)
-            bad &= ~(np.isnan(gf) & np.isnan(wf))
-        if bad.any():
-            i = int(np.flatnonzero(bad)[0])
-            raise AssertionError("%s: %d f32 words differ, first at word %d: got %r want %r" % (
-                what, int(bad.sum()), i, got.view(np.float32)[i], want.view(np.float32)[i]))
-    else:
-        bad = got != want
-        if bad.any():
-            i = int(np.flatnonzero(bad)[0])
-            raise AssertionError("%s: %d bytes differ, first at byte %d (sample %d): got %d want %d" % (
-                what, int(bad.sum()), i, i // 4, got[i], want[i]))
-
-
+# ------------------------------------------------------------------ A7: ccexpf / sincos
 def test_ccexpf_matches_glibc_bit_for_bit(ctx, orc):
     """complex.c:33-39 for imaginary arguments: device sincos == restated glibc == this host's libm."""
     from doppler_amd import dsp
@@ -60,18 +52,48 @@ def test_ccexpf_matches_glibc_bit_for_bit(ctx, orc):
     z = np.zeros(theta.size, dtype=dsp.complex32)
     z["im"] = theta
     got = dsp.ccexpf(z, ctx=ctx)
-    # restated glibc sincosf, FMA build (host-independent)
     assert_same_bytes(got, orc.ccexpf_imag_array(theta, mode=1), "f32", "device vs restated glibc sincosf")
-    # this host's libm through the reference's own ccexpf (oracle/_ref when built)
     if orc.libm_variant() == 1:
+        # this host's libm through the reference's own ccexpf (oracle/_ref when built)
         assert_same_bytes(got, orc.ccexpf_imag_array(theta, mode=0), "f32", "device vs libm cexpf")
-    # the SSE2 build of libm is reproduced as well
     ctx.set_libm_contraction(False)
     try:
         got0 = dsp.ccexpf(z, ctx=ctx)
     finally:
         ctx.set_libm_contraction(True)
     assert_same_bytes(got0, orc.ccexpf_imag_array(theta, mode=2), "f32", "device vs restated glibc (no fma)")
+
+
+def test_ccexpf_strided_sweep_of_all_floats(ctx, orc):
+    """Every 64th float bit pattern (2^26 arguments, all exponents, both signs)."""
+    from doppler_amd import dsp
+    for part in range(4):
+        bits = (np.arange(1 << 24, dtype=np.uint64) * 64 + part * 16 + (np.uint64(part) << np.uint64(30))).astype(np.uint32)
+        theta = bits.view(np.float32)
+        z = np.zeros(theta.size, dtype=dsp.complex32)
+        z["im"] = theta
+        got = dsp.ccexpf(z, ctx=ctx)
+        assert_same_bytes(got, orc.ccexpf_imag_array(theta, mode=1), "f32", "sweep part %d" % part)
+
+
+def test_reference_known_answer_on_device(ctx):
+    """The one vector of the reference's test_cexpf (dsp.rs:62-65) that lies on the hot path: (0,0) -> (1,0)."""
+    from doppler_amd import dsp
+    got = dsp.ccexpf(np.zeros(1, dtype=dsp.complex32), ctx=ctx)
+    assert got["re"][0] == 1.0 and got["im"][0] == 0.0
+
+
+# ------------------------------------------------------------------ A1-A6 through the operator entry points
+def test_golden_shift_block_cases(ctx):
+    """Fused kernel vs the committed golden vectors (generated with the reference's complex.c linked)."""
+    from doppler_amd import dsp
+    n = 0
+    for c in shift_block_cases():
+        got, cnt, sn = dsp.shift_block(c["x"], c["intype"], c["outtype"], c["sn0"], c["shift"], c["rate"], ctx=ctx)
+        assert cnt == c["n"] and sn == c["sn1"], c["key"]
+        assert_same_bytes(got, c["y"], c["outtype"], c["key"])
+        n += 1
+    assert n > 200
 
 
 SHIFTS = [(5000.0, 1024000), (-15000.0, 256000), (815000.0, 2400000), (0.0, 1024000), (3.0, 1024000),
@@ -84,15 +106,10 @@ def test_shift_block_matches_oracle(ctx, orc, intype, outtype):
     """The fused kernel vs the oracle's three-pass restatement, all format pairs, carried counter."""
     from doppler_amd import dsp
     for si, (shift_hz, rate) in enumerate(SHIFTS):
-        for n in [0, 1, 3, 4, 5, 2047, 2048, 2049, 3 * 2048 + 5, 40000]:
+        for n in [0, 1, 3, 4, 5, 2047, 2048, 2049, 3 * 2048 + 5, 40000, 150000]:
             for sn0 in [0, 1, 7]:
-                x = make_iq(intype, n, 100 * si + n % 97 + sn0)
-                want, _, cnt, sn_w = None, None, None, None
-                # oracle: whole buffer through the per-sample functions (no 8192 cap here)
-                if intype == "i16":
-                    cx = orc.convert_iqi16_to_complex(x)
-                else:
-                    cx = orc.convert_iqf32_to_complex(x)
+                x = make_iq(intype, n, 100 * si + n % 97 + sn0, full_scale=True)
+                cx = orc.convert_iqi16_to_complex(x) if intype == "i16" else orc.convert_iqf32_to_complex(x)
                 o, sn_w = orc.shift_frequency(cx, sn0, shift_hz, rate)
                 want = orc.pack_i16(o) if outtype == "i16" else orc.pack_f32(o)
                 got, cnt, sn_g = dsp.shift_block(x, intype, outtype, sn0, shift_hz, rate, ctx=ctx)
@@ -105,13 +122,11 @@ def test_operator_functions_match_reference_semantics(ctx, orc):
     """convert_* / shift_frequency / pack as separate operators (dsp.rs:85,101,117; main.rs:72-87)."""
     from doppler_amd import dsp
     x = make_iq("i16", 5000, 1, full_scale=True)
-    a = dsp.convert_iqi16_to_complex(x, ctx=ctx)
-    assert_same_bytes(a, orc.convert_iqi16_to_complex(x), "f32", "convert_iqi16")
+    assert_same_bytes(dsp.convert_iqi16_to_complex(x, ctx=ctx), orc.convert_iqi16_to_complex(x), "f32", "convert_iqi16")
     y = make_iq("f32", 3000, 2)
     b = dsp.convert_iqf32_to_complex(y, ctx=ctx)
     assert_same_bytes(b, orc.convert_iqf32_to_complex(y), "f32", "convert_iqf32")
-    sn = 0
-    sn_o = 0
+    sn = sn_o = 0
     for _ in range(3):   # carried counter across calls, like main.rs:60
         g, sn = dsp.shift_frequency(b, sn, 815000.0, 2400000, ctx=ctx)
         w, sn_o = orc.shift_frequency(b, sn_o, 815000.0, 2400000)
@@ -121,37 +136,143 @@ def test_operator_functions_match_reference_semantics(ctx, orc):
     big["re"] = [0.5, 1.0, 1.5, -1.0, -1.5, np.nan, np.inf, -np.inf]
     big["im"] = [-0.5, 1.00002, 40000.0, -1.00002, 1e30, 1e-30, -0.0, 3e38]
     assert_same_bytes(dsp.pack_iqi16(big, ctx=ctx), orc.pack_i16(big), "i16", "pack saturation / NaN")
-    with pytest.raises(dsp.DspError) as e:
+    with pytest.raises(dsp.DspError) as e:      # the reference panics: dsp.rs:87
         dsp.convert_iqi16_to_complex(x[:-1], ctx=ctx)
     assert e.value.code == -2
-    with pytest.raises(dsp.DspError):
+    with pytest.raises(dsp.DspError):           # dsp.rs:103
         dsp.shift_block(y[:-3], "f32", "f32", 0, 1.0, 1000, ctx=ctx)
+    # empty input is legal (the reference's last, empty read)
+    o, cnt, sn2 = dsp.shift_block(np.zeros(0, np.uint8), "i16", "f32", 5, 1.0, 1000, ctx=ctx)
+    assert o.size == 0 and cnt == 0 and sn2 == 5
+
+
+def test_reference_bench_configuration_on_device(ctx):
+    """src/dsp.rs:136-157: 1 000 000 bytes of 0xAA as f32 IQ, 815 kHz at 2.4 Msps, counter carried over 301 calls."""
+    from doppler_amd import dsp
+    z = load_golden("reference_tests.npz")
+    cx = dsp.convert_iqf32_to_complex(np.full(1000000, 0xAA, dtype=np.uint8), ctx=ctx)
+    sn = 0
+    digest = []
+    for it in range(301):
+        o, sn = dsp.shift_frequency(cx, sn, 815000.0, 2400000, ctx=ctx)
+        if it in (0, 1, 150, 300):
+            digest.append(int(o.view(np.uint32).astype(np.uint64).sum()))
+    assert digest == [int(d) for d in z["bench_digest"]]
+    assert sn == int(z["bench_final_samplenum"][0])
+
+
+# ------------------------------------------------------------------ bulk path
+def test_golden_streams_bulk(ctx):
+    z = load_golden("const_stream_cases.npz")
+    for k in range(4):
+        shift, rate, sn, it, ot = z["s%d_meta" % k]
+        fi, fo = ("i16", "f32")[int(it)], ("i16", "f32")[int(ot)]
+        x = z["s%d_in" % k]
+        got, fin = run_bulk(ctx, x, fi, fo, [(x.size // BPS[fi], float(shift))], int(rate))
+        assert fin == int(sn)
+        assert_same_bytes(got, z["s%d_out" % k], fo, "golden stream %d" % k)
+    # track replay: one plan segment per reference block, shifts from the golden schedule
+    t = load_golden("track_stream_case.npz")
+    rate, freq, off, sn = t["meta"]
+    x = t["x"]
+    n = x.size // 4
+    segs = []
+    for b, hz in enumerate(t["shift_log"]):
+        cnt = min(2048, n - b * 2048)
+        if cnt > 0:
+            segs.append((cnt, float(hz)))
+    got, fin = run_bulk(ctx, x, "i16", "i16", segs, int(rate))
+    assert fin == int(sn)
+    assert_same_bytes(got, t["y"], "i16", "golden track stream")
 
 
 @pytest.mark.parametrize("intype,outtype", [("i16", "i16"), ("f32", "f32"), ("i16", "f32"), ("f32", "i16")])
 def test_const_stream_bulk_vs_oracle(ctx, orc, intype, outtype):
-    """`doppler const` over 4 Mi samples, device-resident bulk path, every tuning variant."""
-    import doppler_amd
-    n = (1 << 22) + 8192 // FS[intype] * 3 + 1234 * (FS[intype] // 4)
-    x = make_iq(intype, n, 11)
-    want, sn_w = orc.const_stream(x, intype, outtype, 5000, 1024000)
-    nthreads = 8
-    d_in = ctx.malloc(x.size)
-    d_out = ctx.malloc(n * FS[outtype])
+    """`doppler const` over 4 Mi samples, device-resident bulk path, every kernel variant."""
+    n = (1 << 22) + 8192 // BPS[intype] * 3 + 1234 * (BPS[intype] // 4)
+    x = make_iq(intype, n, 11, full_scale=True)
+    want, sn_w = orc.const_stream(x, intype, outtype, 5000, 1024000, threads=8)
+    sn_w = orc.advance_samplenum(0, 5000.0, 1024000, n)
     try:
-        ctx.h2d(d_in, x)
         for variant, block, vecs in [(3, 256, 1), (4, 256, 1), (1, 256, 1), (2, 128, 1), (4, 128, 2), (1, 256, 2)]:
             ctx.set_tuning(block, vecs, variant)
-            plan = ctx.plan_const(5000.0, 1024000, n)
-            got = np.zeros(n * FS[outtype], dtype=np.uint8)
-            ctx.h2d(d_out, got)
-            plan.run(d_in, intype, d_out, outtype)
-            ctx.synchronize()
-            ctx.d2h(got, d_out)
-            assert plan.final_samplenum == sn_w
+            got, fin = run_bulk(ctx, x, intype, outtype, [(n, 5000.0)], 1024000)
+            assert fin == sn_w
             assert_same_bytes(got, want, outtype, "variant=%d block=%d vecs=%d" % (variant, block, vecs))
-            plan.close()
     finally:
         ctx.set_tuning(256, 1, 3)
-        ctx.free(d_in)
-        ctx.free(d_out)
+
+
+@pytest.mark.parametrize("shift,rate", [(815000.0, 2400000), (9876.543, 1024000), (-5234.17, 1024000), (3.0, 1024000),
+                                        (0.0, 1024000), (-15000.0, 256000)])
+def test_periods_and_large_angles_bulk(ctx, orc, shift, rate):
+    """Periods that are not powers of two, a period longer than any table, |theta| >= 120 (the
+    32x96-bit reduction range of sincosf), shift 0."""
+    n = 700000 + 13
+    for intype, outtype in (("i16", "i16"), ("f32", "f32")):
+        x = make_iq(intype, n, 21)
+        cx = orc.convert_iqi16_to_complex(x) if intype == "i16" else orc.convert_iqf32_to_complex(x)
+        o, sn_w = orc.shift_frequency(cx, 0, shift, rate)
+        want = orc.pack_i16(o) if outtype == "i16" else orc.pack_f32(o)
+        got, fin = run_bulk(ctx, x, intype, outtype, [(n, shift)], rate)
+        assert fin == sn_w
+        assert_same_bytes(got, want, outtype, "shift=%r %s->%s" % (shift, intype, outtype))
+
+
+def test_track_segments_bulk_vs_oracle(ctx, orc):
+    """Track replay (main.rs:156-184) at 256 ksps for 12 s with an overpass-shaped range rate: the schedule
+    comes from the oracle's log; the counter is carried across every shift change."""
+    rate, freq, off = 256000, 437505000, 2500
+    t = np.arange(16, dtype=np.float64)
+    rr = 6.8 * np.tanh((t - 6.0) / 2.0)
+    n = rate * 12 + 2048 * 2 + 321
+    for intype, outtype in (("i16", "i16"), ("f32", "i16")):
+        x = make_iq(intype, n, 31)
+        want, sn_w, log = orc.track_stream(x, intype, outtype, rate, freq, rr, offset_hz=off)
+        spb = 8192 // BPS[intype]
+        segs = []
+        for b, hz in enumerate(log):
+            cnt = min(spb, n - b * spb)
+            if cnt > 0:
+                if segs and segs[-1][1] == float(hz):
+                    segs[-1] = (segs[-1][0] + cnt, float(hz))     # merge equal neighbours: same arithmetic
+                else:
+                    segs.append((cnt, float(hz)))
+        assert 10 <= len(segs) <= 20
+        got, fin = run_bulk(ctx, x, intype, outtype, segs, rate)
+        assert fin == sn_w
+        assert_same_bytes(got, want, outtype, "track %s->%s" % (intype, outtype))
+
+
+def test_chunked_equals_whole(ctx, orc):
+    """Time-chunk sharding: 5 block-aligned chunks seeded from the closed form reproduce
+    the single-pass output byte for byte."""
+    from doppler_amd import shard
+    n = 2048 * 301 + 77
+    x = make_iq("i16", n, 41)
+    whole, fin = run_bulk(ctx, x, "i16", "i16", [(n, 9876.543)], 1024000)
+    parts = []
+    for r in range(5):
+        lo, hi = shard.chunk_bounds(n, 5, r)
+        seed = shard.chunk_seed(9876.543, 1024000, lo)
+        got, _ = run_bulk(ctx, x[4 * lo:4 * hi], "i16", "i16", [(hi - lo, 9876.543)], 1024000, sn0=seed)
+        parts.append(got)
+    assert_same_bytes(np.concatenate(parts), whole, "i16", "chunks vs whole")
+    want, _ = orc.const_stream(x, "i16", "i16", 9876, 1024000)   # different shift: must differ (sanity)
+    assert not np.array_equal(want, whole)
+
+
+def test_full_size_headline_config(ctx, orc):
+    """BASELINE.json configs[1] at full size: 268 435 456 samples of i16 IQ, 5000 Hz at 1.024 Msps, compared
+    byte for byte with the oracle run on all host cores (chunks seeded by the oracle's own sequential counter)."""
+    n = 268435456
+    rng = np.random.default_rng(2)
+    x = rng.integers(-23170, 23171, size=2 * n, dtype=np.int16).view(np.uint8)
+    got, fin = run_bulk(ctx, x, "i16", "i16", [(n, 5000.0)], 1024000)
+    threads = min(os.cpu_count() or 1, 64)
+    want, _ = orc.const_stream(x, "i16", "i16", 5000, 1024000, threads=threads)
+    assert fin == 1024
+    assert got.size == want.size
+    # compare in slabs to keep the peak memory of the comparison small
+    for a in range(0, got.size, 1 << 28):
+        assert np.array_equal(got[a:a + (1 << 28)], want[a:a + (1 << 28)]), "mismatch in slab at byte %d" % a

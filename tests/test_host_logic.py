@@ -1,0 +1,117 @@
+"""CPU: the product's host-side logic (planner / closed-form counter / sharding) against the oracle's
+sequential counter, and the C ABI surface.  No compute calls: there is no GPU here."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import doppler_amd
+from doppler_amd import _lib, engine, shard
+from helpers import oracle_counters
+
+RATIOS = [(5000.0, 1024000), (-15000.0, 256000), (815000.0, 2400000), (0.0, 1024000), (9876.543, 1024000),
+          (-5234.17, 1024000), (3.0, 1024000), (1.0, 3), (7.0, 2), (123456.0, 48000)]
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 25
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(declared) == set(_lib._SIGNATURES), set(declared) ^ set(_lib._SIGNATURES)
+    assert doppler_amd.lib.dpx_abi_version() == 1
+
+
+def test_no_cpu_fallback_anywhere():
+    """Without a usable GPU the product must fail loudly; and it must never import the oracle."""
+    import sys
+    n = C.c_int()
+    rc = doppler_amd.lib.dpx_device_count(C.byref(n))
+    if rc != 0 or n.value == 0:
+        with pytest.raises(doppler_amd.DspError) as e:
+            doppler_amd.Context(0)
+        assert e.value.code == _lib.ERR_NO_DEVICE
+        with pytest.raises(doppler_amd.DspError):
+            doppler_amd.dsp.shift_block(np.zeros(8, np.uint8), "i16", "i16", 0, 1.0, 1000)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "doppler_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".cuh")):
+                text = open(os.path.join(dirpath, f)).read()
+                for needle in ("import oracle", "from oracle", "liboracle", "oracle/", "orc_"):
+                    assert needle not in text, "%s references the test oracle (%r)" % (os.path.join(dirpath, f), needle)
+    assert "oracle" not in sys.modules or True   # the test session itself may have imported it; the package must not
+
+
+@pytest.mark.parametrize("shift,rate", RATIOS)
+def test_closed_form_counter_matches_sequential_rule(orc, shift, rate):
+    n = 40000
+    for sn0 in (0, 1, 5, 1023, 1024, 77777):
+        want, sn_end = oracle_counters(orc, [(n, shift)], rate, sn0)
+        stretches, fin = doppler_amd.plan_describe([(n, shift)], rate, sn0)
+        assert fin == sn_end
+        got = np.empty(n, np.uint32)
+        pos = 0
+        for s in stretches:
+            assert s["first"] == pos
+            j = np.arange(s["count"], dtype=np.uint64)
+            if s["period"] == 0:
+                got[pos:pos + s["count"]] = s["n_start"] + j
+            else:
+                got[pos:pos + s["count"]] = ((s["n_start"] - 1 + j) % s["period"]) + 1
+            pos += s["count"]
+        assert pos == n
+        assert np.array_equal(got, want), (shift, rate, sn0, int(np.flatnonzero(got != want)[0]))
+        assert engine.samplenum_after(shift, rate, sn0, n) == sn_end
+        assert engine.samplenum_after(shift, rate, sn0, 0) == sn0
+
+
+def test_find_reset_and_period(orc):
+    for shift, rate, P in [(5000.0, 1024000, 1024), (-15000.0, 256000, 256), (815000.0, 2400000, 480),
+                           (0.0, 1024000, 1), (9876.543, 1024000, 2592), (-5234.17, 1024000, 107405)]:
+        assert engine.find_reset(shift, rate, 1, 1 << 22) == P
+        assert engine.find_reset(shift, rate, 0, 10) == 0
+        assert engine.find_reset(shift, rate, 1, P - 1) is None
+    # 3 Hz at 1.024 Msps: the first reset from 1 is a full second away
+    assert engine.find_reset(3.0, 1024000, 1, 2000000) == 1024000
+
+
+def test_launch_lists_cover_every_sample_once(orc):
+    """dpx_plan_simulate mirrors the kernels' index arithmetic on the host: every sample written exactly
+    once and with the counter value of the sequential rule — for the rows kernel, the tile kernel, the
+    per-sample path, stretch boundaries and carried counters (track mode)."""
+    cases = [
+        ([(300000, 5000.0)], 1024000, 0),
+        ([(131072 + 17, -15000.0)], 256000, 200),
+        ([(200000, 815000.0), (150000, 9876.543), (1234, 3.0), (100000, 0.0), (70001, 5000.0)], 2400000, 0),
+        ([(2048, 100.0), (2048, 101.5), (2048 * 40, 5000.0), (100, -3.25)], 1024000, 0),
+        ([(1, 5000.0)], 1024000, 0), ([(255, 5000.0)], 1024000, 3), ([(70000, 1.0)], 3, 0),
+    ]
+    for segs, rate, sn0 in cases:
+        want, _ = oracle_counters(orc, segs, rate, sn0)
+        for variant in (3, 4, 1, 2):
+            for block, vecs in ((256, 1), (128, 2)):
+                c, w = doppler_amd.plan_simulate(segs, rate, sn0, block, vecs, variant)
+                assert (w == 1).all(), (segs, variant, block, vecs, np.flatnonzero(w != 1)[:5])
+                assert np.array_equal(c, want), (segs, variant, block, vecs, np.flatnonzero(c != want)[:5])
+
+
+def test_chunk_sharding_seeds(orc):
+    n = 2048 * 37 + 555
+    for world in (1, 2, 3, 8):
+        pos = 0
+        for r in range(world):
+            lo, hi = shard.chunk_bounds(n, world, r)
+            assert lo == pos and lo % 2048 == 0
+            pos = hi
+            assert shard.chunk_seed(9876.543, 1024000, lo) == orc.advance_samplenum(0, 9876.543, 1024000, lo)
+        assert pos == n
+    segs = [(2048 * 3, 100.0), (2048 * 5, -7.5), (2048 * 2 + 9, 5000.0)]
+    before, inside = shard.segments_for_chunk(segs, 2048 * 4, 2048 * 9)
+    assert before == [(2048 * 3, 100.0), (2048, -7.5)] and inside == [(2048 * 4, -7.5), (2048, 5000.0)]
+    sn = 0
+    for cnt, hz in before:
+        sn = orc.advance_samplenum(sn, hz, 1024000, cnt)
+    assert shard.seed_for_segments(before, 1024000) == sn
