@@ -169,9 +169,12 @@ __device__ __forceinline__ void one_sample(const uint8_t *in, uint8_t *out, cons
 }
 
 // ---- rows kernel: one wavefront, kRowsR rows of one tabulated periodic stretch
-template <int FMT> struct RowVec;   // S samples of one lane in one row: 16 bytes in
-template <> struct RowVec<DPX_FMT_I16> { static constexpr int S = 4; };
-template <> struct RowVec<DPX_FMT_F32> { static constexpr int S = 2; };
+// S samples per lane per row: the wider of the two sides moves as one 16-byte vector per lane,
+// the narrower side as 16 or 8 bytes (measured: 8-byte accesses on the narrow side are free,
+// two 16-byte stores at a 32-byte lane stride halve the rate).
+template <int IN_FMT, int OUT_FMT> struct RowVec {
+    static constexpr int S = (IN_FMT == DPX_FMT_I16 && OUT_FMT == DPX_FMT_I16) ? 4 : 2;
+};
 
 // Argument order matters: the first 16 dwords are preloaded into SGPRs at wavefront
 // launch (-amdgpu-kernarg-preload-count=16), and they are exactly what the matrix
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
                                                           const DevSeg *__restrict__ segs,
                                                           RowsArgs ra)
 {
-    constexpr int S = RowVec<IN_FMT>::S;
+    constexpr int S = RowVec<IN_FMT, OUT_FMT>::S;
     constexpr int R = kRowsR;
     constexpr int IB = Fmt<IN_FMT>::kBytes, OB = Fmt<OUT_FMT>::kBytes;
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
@@ -200,10 +203,12 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
         if (cs0 >= L) return;                                  // ragged last column slice
         const uint64_t g0 = A + (uint64_t)rg * (R * (uint64_t)L) + cs0;
 
-        u32x4 q[R];
+        constexpr int QW = S * IB / 4;                         // input dwords per lane per row: 4 or 2
+        typedef uint32_t qvec __attribute__((ext_vector_type(QW)));
+        qvec q[R];
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            q[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in + (g0 + (uint64_t)r * L) * IB));
+            q[r] = __builtin_nontemporal_load(reinterpret_cast<const qvec *>(in + (g0 + (uint64_t)r * L) * IB));
 
         // S correctors, shared by the R rows: table origin is sample A, so the index is cs0
         const u32x4 *tp = reinterpret_cast<const u32x4 *>(tab + cs0);
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
     if (whole && sg.lut_len != 0 && !(sg.flags & kSegRows)) {
         // ---- tabulated correctors: phase of t0 within the period, then straight indexing
         const uint32_t P = sg.period;
-        // (c0 + t0) mod P with t0 = tile * TILE, all in 32 bits: P <= kLutMaxEntries = 2^13
+        // (c0 + t0) mod P with t0 = tile * TILE, all in 32 bits: (tile mod P) * tmod < 2^18 * 2^11
         uint32_t ph = sg.c0 + (((uint32_t)tile % P) * sg.tmod) % P;   // tile < 2^32 (checked on the host)
         ph = (ph >= P) ? ph - P : ph;
         const float2 *tab = lut_pool + sg.lut_off + ph;
@@ -462,7 +467,7 @@ static int rows_t(const void *d_in, void *d_out, const DevSeg *d_segs, const voi
     const uint8_t *in = static_cast<const uint8_t *>(d_in);
     uint8_t *out = static_cast<uint8_t *>(d_out);
     const float2 *lut = static_cast<const float2 *>(d_lut);
-    constexpr uint32_t S = RowVec<IN_FMT>::S;
+    constexpr uint32_t S = RowVec<IN_FMT, OUT_FMT>::S;
     const uint32_t cols = (r.L + kRowsLanes * S - 1) / (kRowsLanes * S);
     const uint64_t n_main = r.n_rg * cols;
     const uint64_t ragged = (r.A - r.r0) + (r.r1 - r.B);

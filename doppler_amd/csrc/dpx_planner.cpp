@@ -125,7 +125,7 @@ namespace {
 constexpr uint64_t kRowsMinSamples = 1u << 16;   // below this a stretch stays on the tile kernel
 constexpr uint64_t kAbsorbMax = 4096;            // neighbouring crumbs a rows launch may evaluate itself
 
-// Row length for period P: a multiple of lcm(P, 4) not above kLutMaxEntries.  Preference order:
+// Row length for period P: a multiple of lcm(P, 4) not above kRowsMaxL.  Preference order:
 // (1) a multiple of 32 samples, so that every row starts on a 128-byte line (a wavefront's
 // 1 KiB piece then never shares a line with a wavefront on another XCD — measured: a 16-byte
 // skew of the matrix origin alone costs ~20 %); (2) fewest idle lanes in the last 256-sample
@@ -135,10 +135,10 @@ uint32_t pick_row_length(uint32_t P)
     uint64_t g = P, h = 4;
     while (h) { const uint64_t t = g % h; g = h; h = t; }
     const uint64_t base = (uint64_t)P / g * 4;
-    if (base > kLutMaxEntries) return 0;
+    if (base > kRowsMaxL) return 0;
     uint32_t best = 0;
     double best_score = -1.0;
-    for (uint64_t L = base; L <= kLutMaxEntries; L += base) {
+    for (uint64_t L = base; L <= kRowsMaxL && L <= 64 * base; L += base) {
         const double eff = (double)L / (256.0 * (double)((L + 255) / 256));
         const double score = eff + (L % 32 == 0 ? 1.0 : 0.0);
         if (score > best_score + 1e-9) { best_score = score; best = (uint32_t)L; }
