@@ -78,16 +78,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # DPX_BENCH_SHARE_GPU=1 (development only): every rank uses GPU 0 and gloo, to exercise the
+    # multi-rank code path on a one-GPU box; the numbers of such a run mean nothing.
+    share = os.environ.get("DPX_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     import doppler_amd
     from doppler_amd import shard
 
-    ctx = doppler_amd.Context(local_rank)
+    ctx = doppler_amd.Context(dev_index)
     n = N_SAMPLES
     # rank r owns global samples [r*n, (r+1)*n) of the world*n-sample stream: block-aligned chunk,
     # counter seeded from the closed form of dsp.rs:125-130
@@ -106,6 +113,7 @@ def main():
         plan.run(x.data_ptr(), "i16", out.data_ptr(), "i16", stream.cuda_stream)
 
     def barrier():
+        torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)

@@ -5,6 +5,7 @@
 
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -125,22 +126,31 @@ namespace {
 constexpr uint64_t kRowsMinSamples = 1u << 16;   // below this a stretch stays on the tile kernel
 constexpr uint64_t kAbsorbMax = 4096;            // neighbouring crumbs a rows launch may evaluate itself
 
-// Row length for period P: a multiple of lcm(P, 4) not above kRowsMaxL.  Preference order:
-// (1) a multiple of 32 samples, so that every row starts on a 128-byte line (a wavefront's
-// 1 KiB piece then never shares a line with a wavefront on another XCD — measured: a 16-byte
-// skew of the matrix origin alone costs ~20 %); (2) fewest idle lanes in the last 256-sample
-// column slice.  Returns 0 if no multiple fits.
+// Row length for period P: a multiple of lcm(P, 4) not above kRowsMaxL, scored from measurements on
+// MI355X (profiles/r01_membench.md section 4), i16 stream, GB/s relative to the best case:
+//   rows that do not start on a 128-byte line (L % 32 != 0): -20 % (a wavefront's 1 KiB piece then
+//     shares lines with wavefronts running on other XCDs);
+//   idle lanes in the last 256-sample column slice: proportional;
+//   rows that are not a whole number of 4 KiB pages (L % 1024 != 0): about -3 %;
+//   table size: about -2 % at 256 KiB, -3 % at 1 MiB (no longer L1-resident).
+// Returns 0 if no multiple fits.
 uint32_t pick_row_length(uint32_t P)
 {
     uint64_t g = P, h = 4;
     while (h) { const uint64_t t = g % h; g = h; h = t; }
     const uint64_t base = (uint64_t)P / g * 4;
     if (base > kRowsMaxL) return 0;
+    if (const char *e = getenv("DPX_ROWS_MULT")) {   // measurement override: L = mult * lcm(P, 4)
+        const uint64_t L = base * (uint64_t)atoi(e);
+        return (L >= base && L <= kRowsMaxL) ? (uint32_t)L : 0;
+    }
     uint32_t best = 0;
-    double best_score = -1.0;
-    for (uint64_t L = base; L <= kRowsMaxL && L <= 64 * base; L += base) {
-        const double eff = (double)L / (256.0 * (double)((L + 255) / 256));
-        const double score = eff + (L % 32 == 0 ? 1.0 : 0.0);
+    double best_score = -1e9;
+    for (uint64_t L = base; L <= kRowsMaxL; L += base) {
+        double score = (double)L / (256.0 * (double)((L + 255) / 256));
+        if (L % 32 != 0) score -= 0.20;
+        if (L % 1024 != 0) score -= 0.03;
+        if (L > 1024) score -= 0.03 * log2((double)L / 1024.0) / 7.0;
         if (score > best_score + 1e-9) { best_score = score; best = (uint32_t)L; }
     }
     return best;
