@@ -11,9 +11,9 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-f
             -Wall -Wno-unused-function -Iinclude
 
 LIB := $(LIBDIR)/libdoppler_hip.so
-OBJS := $(LIBDIR)/dpx_kernels.o $(LIBDIR)/dpx_api.o $(LIBDIR)/dpx_planner.o
+OBJS := $(LIBDIR)/dpx_kernels.o $(LIBDIR)/dpx_api.o $(LIBDIR)/dpx_planner.o $(LIBDIR)/orbit.o $(LIBDIR)/schedule.o
 
-all: lib oracle
+all: lib cli oracle
 
 lib: $(LIB)
 
@@ -23,7 +23,7 @@ $(LIBDIR)/dpx_kernels.o: $(CSRC)/dpx_kernels.hip $(CSRC)/dpx_sincos.cuh $(CSRC)/
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -mllvm -amdgpu-kernarg-preload-count=16 -c $< -o $@
 
-$(LIBDIR)/dpx_api.o: $(CSRC)/dpx_api.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h include/doppler_hip.h
+$(LIBDIR)/dpx_api.o: $(CSRC)/dpx_api.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h $(CSRC)/host/orbit.h $(CSRC)/host/schedule.h include/doppler_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
@@ -31,14 +31,27 @@ $(LIBDIR)/dpx_planner.o: $(CSRC)/dpx_planner.cpp $(CSRC)/dpx_planner.h $(CSRC)/d
 	@mkdir -p $(LIBDIR)
 	g++ -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -c $< -o $@
 
+$(LIBDIR)/%.o: $(CSRC)/host/%.cpp $(CSRC)/host/orbit.h $(CSRC)/host/schedule.h
+	@mkdir -p $(LIBDIR)
+	g++ -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -c $< -o $@
+
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -Wl,-rpath,$(ROCM)/lib -Wl,-soname,libdoppler_hip.so
+
+# the `doppler` command (stdin -> GPU -> stdout), linked against the C ABI library
+BINDIR := doppler_amd/bin
+cli: $(BINDIR)/doppler
+
+$(BINDIR)/doppler: $(CSRC)/cli/main.cpp $(CSRC)/cli/args.cpp $(CSRC)/cli/args.h $(LIB)
+	@mkdir -p $(BINDIR)
+	$(HIPCC) -O2 -std=c++17 -ffp-contract=off -Wall -Iinclude -x hip --offload-arch=$(ARCH) $(CSRC)/cli/main.cpp $(CSRC)/cli/args.cpp \
+	    -o $@ -L$(LIBDIR) -ldoppler_hip -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,$(ROCM)/lib
 
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -rf $(LIBDIR)
+	rm -rf $(LIBDIR) $(BINDIR)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle clean
+.PHONY: all lib cli oracle clean

@@ -53,6 +53,9 @@ _SIGNATURES = {
     "dpx_samplenum_after": (_i, [_f, _u32, _u32, _u64, _P(_u32)]),
     "dpx_plan_describe": (_i, [_P(Segment), _sz, _u32, _u32, _i, _P(Stretch), _sz, _P(_sz), _P(_u32)]),
     "dpx_plan_simulate": (_i, [_P(Segment), _sz, _u32, _u32, _i, _i, _i, _vp, _vp, _u64]),
+    "dpx_track_schedule": (_i, [_vp, _sz, _u32, _u32, C.c_int32, _i, _i, _u64, _vp, _sz, _P(_sz)]),
+    "dpx_orbit_observe": (_i, [C.c_char_p, C.c_char_p, C.c_double, C.c_double, C.c_double, C.c_double, _vp]),
+    "dpx_orbit_propagate": (_i, [C.c_char_p, C.c_char_p, C.c_double, _vp]),
     "dpx_plan_const": (_i, [_vp, _f, _u32, _u32, _u64, _P(_vp)]),
     "dpx_plan_segments": (_i, [_vp, _P(Segment), _sz, _u32, _u32, _P(_vp)]),
     "dpx_plan_n_samples": (_i, [_vp, _P(_u64)]),

@@ -15,6 +15,8 @@
 #include "../../include/doppler_hip.h"
 #include "dpx_planner.h"
 #include "dpx_types.h"
+#include "host/orbit.h"
+#include "host/schedule.h"
 
 namespace {
 
@@ -426,6 +428,68 @@ int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
     dpx::finalize(plan, g.tile(), variant != 4);
     memset(writes, 0, n_samples);
     dpx::simulate(plan, counters, writes);
+    return DPX_OK;
+}
+
+int dpx_track_schedule(const double *range_rate_km_s, size_t n_table, uint32_t samplerate,
+                       uint32_t frequency_hz, int32_t offset_hz, int has_offset, int in_fmt,
+                       uint64_t in_bytes, float *shift_hz, size_t cap, size_t *n_blocks)
+{
+    if (!range_rate_km_s || n_table == 0 || !n_blocks || (cap && !shift_hz) || !fmt_ok(in_fmt))
+        return fail(DPX_ERR_ARG, "bad argument");
+    dpx::ReplaySchedule sch(
+        [=](int64_t dt) {
+            const size_t i = dt < 0 ? 0 : ((uint64_t)dt >= n_table ? n_table - 1 : (size_t)dt);
+            return range_rate_km_s[i];
+        },
+        samplerate, frequency_hz, has_offset != 0, offset_hz);
+    const size_t bps = bytes_per_sample(in_fmt);
+    uint64_t pos = 0;
+    size_t nb = 0;
+    for (;;) {
+        const uint64_t take = in_bytes - pos < DPX_BUFFER_SIZE ? in_bytes - pos : DPX_BUFFER_SIZE;
+        const float hz = sch.next_block_shift();
+        if (nb < cap) shift_hz[nb] = hz;
+        ++nb;
+        if (take % bps != 0) return fail(DPX_ERR_BLOCK_LEN, "trailing partial sample");
+        pos += take;
+        if (take != DPX_BUFFER_SIZE) break;
+        sch.block_done((size_t)(take / bps));
+    }
+    *n_blocks = nb;
+    return DPX_OK;
+}
+
+int dpx_orbit_observe(const char *l1, const char *l2, double lat_deg, double lon_deg, double alt_m,
+                      double unix_time_s, double out[4])
+{
+    if (!l1 || !l2 || !out) return fail(DPX_ERR_ARG, "bad argument");
+    dpx::Tle tle;
+    std::string err;
+    if (!dpx::tle_parse(l1, l2, &tle, &err)) return fail(DPX_ERR_ARG, "%s", err.c_str());
+    dpx::Sgp4 prop;
+    if (!prop.init(tle, &err)) return fail(DPX_ERR_ARG, "%s", err.c_str());
+    dpx::Observer obs;
+    obs.lat_deg = lat_deg;
+    obs.lon_deg = lon_deg;
+    obs.alt_m = alt_m;
+    const dpx::LookAngles la = prop.observe(obs, unix_time_s);
+    out[0] = la.az_deg;
+    out[1] = la.el_deg;
+    out[2] = la.range_km;
+    out[3] = la.range_rate_km_s;
+    return DPX_OK;
+}
+
+int dpx_orbit_propagate(const char *l1, const char *l2, double tsince_min, double out[6])
+{
+    if (!l1 || !l2 || !out) return fail(DPX_ERR_ARG, "bad argument");
+    dpx::Tle tle;
+    std::string err;
+    if (!dpx::tle_parse(l1, l2, &tle, &err)) return fail(DPX_ERR_ARG, "%s", err.c_str());
+    dpx::Sgp4 prop;
+    if (!prop.init(tle, &err)) return fail(DPX_ERR_ARG, "%s", err.c_str());
+    prop.propagate(tsince_min, out, out + 3);
     return DPX_OK;
 }
 

@@ -136,6 +136,27 @@ int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
                       uint32_t samplenum0, int block, int vecs, int variant,
                       uint32_t *counters, uint8_t *writes, uint64_t n_samples);
 
+/* ------------------------------------------------ track mode, host side (N2)
+ * Host-only.  The per-block shift schedule of `doppler track --time` (reference
+ * src/main.rs:156-184: one-block lag, whole seconds truncated through f32, f32 offset add) for a
+ * stream of in_bytes, with the range rate supplied per whole second (entry t = range rate at
+ * start_time + t s; the last entry is held).  Writes one shift per loop iteration of the reference
+ * (floor(in_bytes / 8192) + 1, the last one belonging to the short or empty final block). */
+int dpx_track_schedule(const double *range_rate_km_s, size_t n_table, uint32_t samplerate,
+                       uint32_t frequency_hz, int32_t offset_hz, int has_offset, int in_fmt,
+                       uint64_t in_bytes, float *shift_hz, size_t cap, size_t *n_blocks);
+
+/* Host-only.  NORAD SGP4 (near-earth) + geodetic observer: what the reference reads from
+ * predict.sat after predict.update(time) (src/main.rs:162-173).  out[4] = azimuth deg,
+ * elevation deg, range km, range rate km/s.  libgpredict is not part of the reference tree:
+ * ORBIT PARITY UNPINNED. */
+int dpx_orbit_observe(const char *tle_line1, const char *tle_line2, double lat_deg, double lon_deg,
+                      double alt_m, double unix_time_s, double out[4]);
+
+/* Host-only.  SGP4 state vector `tsince_min` minutes after the element-set epoch:
+ * out[6] = x, y, z (km), xdot, ydot, zdot (km/s), true-equator mean-equinox frame. */
+int dpx_orbit_propagate(const char *tle_line1, const char *tle_line2, double tsince_min, double out[6]);
+
 /* ----------------------------------------------- bulk API (device pointers) */
 
 /* constant shift over n_samples starting with counter samplenum0 */
