@@ -301,8 +301,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
     if (whole && sg.lut_len != 0 && !(sg.flags & kSegRows)) {
         // ---- tabulated correctors: phase of t0 within the period, then straight indexing
         const uint32_t P = sg.period;
-        // (c0 + t0) mod P with t0 = tile * TILE, all in 32 bits: (tile mod P) * tmod < 2^18 * 2^11
-        uint32_t ph = sg.c0 + (((uint32_t)tile % P) * sg.tmod) % P;   // tile < 2^32 (checked on the host)
+        // (c0 + t0) mod P with t0 = tile * TILE; 32-bit while (tile mod P) * tmod < 2^18 * 2^11
+        uint32_t ph;
+        if (P <= (1u << 18)) ph = sg.c0 + (((uint32_t)tile % P) * sg.tmod) % P;   // tile < 2^32 (checked on the host)
+        else                 ph = sg.c0 + (uint32_t)(t0 % P);
         ph = (ph >= P) ? ph - P : ph;
         const float2 *tab = lut_pool + sg.lut_off + ph;
 #pragma unroll

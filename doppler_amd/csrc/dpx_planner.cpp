@@ -125,6 +125,7 @@ namespace {
 
 constexpr uint64_t kRowsMinSamples = 1u << 16;   // below this a stretch stays on the tile kernel
 constexpr uint64_t kAbsorbMax = 4096;            // neighbouring crumbs a rows launch may evaluate itself
+constexpr size_t kRowsMaxLaunches = 8;           // more tabulated stretches than this: one tile launch instead
 
 // Row length for period P: a multiple of lcm(P, 4) not above kRowsMaxL, scored from measurements on
 // MI355X (profiles/r01_membench.md section 4), i16 stream, GB/s relative to the best case:
@@ -168,8 +169,14 @@ void finalize(PlanResult &plan, uint32_t tile, bool use_rows)
     const size_t ns = plan.segs.size();
     uint64_t pool = 0;
 
-    // ---- which stretches go to the rows kernel
+    // ---- which stretches go to the rows kernel.  Each one is its own launch, so a plan with many
+    // of them (track mode: one per second of stream) is better served by ONE tile-kernel launch over
+    // everything (measured, 600 one-second stretches: 1.14 ms against 1.25 ms).
     std::vector<Interval> covered;
+    size_t eligible = 0;
+    for (const DevSeg &s : plan.segs)
+        if (s.lut_len != 0 && s.count >= kRowsMinSamples && pick_row_length(s.period) != 0) ++eligible;
+    if (eligible > kRowsMaxLaunches) use_rows = false;
     for (size_t i = 0; i < ns; ++i) {
         DevSeg &s = plan.segs[i];
         s.flags = 0;
@@ -315,7 +322,8 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
                 const bool whole = in_mask && t0 >= sg.first && t0 + plan.tile <= sg.first + sg.count;
                 if (whole && sg.lut_len != 0 && !(sg.flags & kSegRows)) {
                     const uint32_t P = sg.period;
-                    uint32_t ph = sg.c0 + (((uint32_t)tile % P) * sg.tmod) % P;
+                    uint32_t ph = P <= (1u << 18) ? sg.c0 + (((uint32_t)tile % P) * sg.tmod) % P
+                                                  : sg.c0 + (uint32_t)(t0 % P);
                     ph = ph >= P ? ph - P : ph;
                     for (uint32_t e = 0; e < plan.tile; ++e) put(t0 + e, ((ph + e) % P) + 1u);
                 } else if (whole && (sg.period == 0 || sg.period >= 4)) {

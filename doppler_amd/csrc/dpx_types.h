@@ -42,7 +42,7 @@ struct StretchView {
 };
 
 constexpr int kSamplesPerLane = 4;          // tile kernel: one 16-byte i16 vector = 4 IQ samples
-constexpr uint32_t kLutMaxEntries = 262144; // longest tile-kernel table (2 MiB: stays in the 4 MiB L2 of an XCD)
+constexpr uint32_t kLutMaxEntries = 4194304; // longest tile-kernel table (32 MiB: beyond L2, inside the 256 MiB Infinity Cache)
 constexpr uint32_t kRowsMaxL = 131072;      // longest rows-kernel row / table (1 MiB)
 constexpr int kHintShift = 16;              // one stretch hint per 65536 samples
 constexpr int kRowsLanes = 64;              // rows kernel: one wavefront per workgroup

@@ -42,10 +42,40 @@ def main():
     ap.add_argument("--rate", type=int, default=1024000)
     ap.add_argument("--variants", default="3,4,1")
     ap.add_argument("--geoms", default="128x1,128x2,256x1,256x2")
+    ap.add_argument("--track", type=int, default=0, help="seconds of a synthetic overpass at --rate (track-mode plan)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
     n = args.n
+    if args.track:
+        import math
+        import time
+        n = args.track * args.rate
+        segs = []
+        for t in range(args.track):     # S-shaped Doppler of a LEO pass at 437.505 MHz, one value per second, f32
+            rr = 6.9 * math.tanh((t - args.track / 2) / (args.track / 8.0))
+            hz = float(torch.tensor(-(rr * 1000.0 / 299792458.0) * 437505000.0 + 5000.0, dtype=torch.float32))
+            segs.append((args.rate, hz))
+        for pair in args.pairs.split(","):
+            it, ot = pair.split(":")
+            x = torch.randint(-23170, 23171, (2 * n,), dtype=torch.int16, device=dev) if it == "i16" else (torch.rand(2 * n, device=dev) * 2 - 1)
+            out = torch.empty(n * BPS[ot], dtype=torch.uint8, device=dev)
+            variant = int(args.variants.split(",")[0])
+            ctx.set_tuning(256, 1, variant)
+            t0 = time.perf_counter()
+            plan = ctx.plan_segments(segs, args.rate)
+            t_plan = time.perf_counter() - t0
+            st = doppler_amd.plan_describe(segs, args.rate)[0]
+            kinds = {"rows_or_tile_table": sum(1 for s_ in st if s_["lut_len"]), "direct": sum(1 for s_ in st if not s_["lut_len"]),
+                     "direct_samples": sum(s_["count"] for s_ in st if not s_["lut_len"])}
+            stream = torch.cuda.current_stream().cuda_stream
+            avg, med, mn = time_launches(lambda: plan.run(x.data_ptr(), it, out.data_ptr(), ot, stream), args.iters)
+            alg = n * (BPS[it] + BPS[ot])
+            print(json.dumps({"kernel": "track", "variant": variant, "pair": pair, "seconds": args.track, "samples": n, "plan_ms": round(t_plan * 1e3, 2),
+                              "stretches": len(st), **kinds, "ms_avg": round(avg, 4), "GBps_avg": round(alg / avg / 1e6, 1),
+                              "Msps_avg": round(n / avg / 1e3, 0)}), flush=True)
+            plan.close()
+        return
     stream = torch.cuda.current_stream().cuda_stream
     for pair in args.pairs.split(","):
         it, ot = pair.split(":")
