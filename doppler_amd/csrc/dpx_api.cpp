@@ -48,7 +48,7 @@ struct dpx_ctx {
     int n_cu = 0;
     bool fma = true;          // libm variant whose sincosf the kernels reproduce
     int block = 256;          // lanes per workgroup (128 or 256)
-    int vecs = 1;             // 4-sample groups per lane (1, 2 or 4)
+    int vecs = 1;             // 4-sample groups per lane (1 or 2)
     int variant = 0;
     bool use_rows = true;     // false: tile kernel only (measurement A/B)
     hipStream_t stream = nullptr;   // internal stream of the host-pointer entry points

@@ -51,7 +51,7 @@ constexpr int kRowsR = 2;                   // rows per workgroup (share one set
 // tile-kernel geometry
 struct LaunchGeom {
     int block;    // 128 or 256 lanes per workgroup
-    int vecs;     // 4-sample groups per lane: 1, 2 or 4
+    int vecs;     // 4-sample groups per lane: 1 or 2
     uint32_t tile() const { return (uint32_t)block * kSamplesPerLane * (uint32_t)vecs; }
 };
 

@@ -276,3 +276,33 @@ def test_full_size_headline_config(ctx, orc):
     # compare in slabs to keep the peak memory of the comparison small
     for a in range(0, got.size, 1 << 28):
         assert np.array_equal(got[a:a + (1 << 28)], want[a:a + (1 << 28)]), "mismatch in slab at byte %d" % a
+
+
+def test_special_values_and_degenerate_ratios(ctx, orc):
+    """f32 inputs with NaN / inf / subnormals / signed zeros / huge magnitudes, i16 full-scale corners, and
+    ratios that are inf or NaN (samplerate 0): outputs equal the oracle's (any NaN matches any NaN)."""
+    from doppler_amd import dsp
+    specials = np.array([0.0, -0.0, 1e-45, -1e-45, 1.17549435e-38, 5e-39, 1.0, -1.0, 0.99999994, 3.4028235e38,
+                         -3.4028235e38, np.inf, -np.inf, np.nan, 32767.5 / 32767.0, -32768.9 / 32767.0, 1e-20, 65504.0],
+                        dtype=np.float32)
+    rng = np.random.default_rng(12)
+    re = rng.choice(specials, size=20000)
+    im = rng.choice(specials, size=20000)
+    x = np.empty(40000, dtype=np.float32)
+    x[0::2], x[1::2] = re, im
+    xb = x.view(np.uint8)
+    for shift, rate in [(5000.0, 1024000), (815000.0, 2400000), (0.0, 1024000), (5000.0, 0), (0.0, 0), (3.0e38, 1)]:
+        for outtype in ("f32", "i16"):
+            cx = orc.convert_iqf32_to_complex(xb)
+            o, sn_w = orc.shift_frequency(cx, 0, shift, rate)
+            want = orc.pack_i16(o) if outtype == "i16" else orc.pack_f32(o)
+            got, cnt, sn_g = dsp.shift_block(xb, "f32", outtype, 0, shift, rate, ctx=ctx)
+            assert sn_g == sn_w
+            assert_same_bytes(got, want, outtype, "specials shift=%r rate=%d out=%s" % (shift, rate, outtype))
+    corners = np.array([32767, -32768, -32768, 32767, 0, -1, 1, 0, 32767, 32767, -32768, -32768], dtype=np.int16)
+    xi = np.tile(corners, 1000).view(np.uint8)
+    for shift, rate in [(5000.0, 1024000), (-15000.0, 256000), (12345.678, 48000)]:
+        cx = orc.convert_iqi16_to_complex(xi)
+        o, _ = orc.shift_frequency(cx, 0, shift, rate)
+        got, _, _ = dsp.shift_block(xi, "i16", "i16", 0, shift, rate, ctx=ctx)
+        assert_same_bytes(got, orc.pack_i16(o), "i16", "i16 corners (saturating cast)")

@@ -115,3 +115,26 @@ def test_chunk_sharding_seeds(orc):
     for cnt, hz in before:
         sn = orc.advance_samplenum(sn, hz, 1024000, cnt)
     assert shard.seed_for_segments(before, 1024000) == sn
+
+
+def test_counter_wraps_like_u32(orc):
+    """`*samplenum += 1` on a u32 wraps to 0 (release-build semantics, stated in oracle/doppler_oracle.c); 0 then
+    resets to 1.  A ratio that never produces an integer near 2^32 keeps the counter climbing to the wrap."""
+    shift, rate = 0.3, 1000003          # ratio ~3e-7: ratio*n ~ 1288.49 near n = 2^32, never an integer there
+    sn0 = (1 << 32) - 150
+    want, sn_end = oracle_counters(orc, [(400, shift)], rate, sn0)
+    assert want[149] == (1 << 32) - 1 and want[150] == 0 and want[151] == 1
+    for variant in (3, 4, 1):
+        c, w = doppler_amd.plan_simulate([(400, shift)], rate, sn0, 256, 1, variant)
+        assert (w == 1).all() and np.array_equal(c, want)
+    st, fin = doppler_amd.plan_describe([(400, shift)], rate, sn0)
+    assert fin == sn_end
+
+
+def test_degenerate_ratios(orc):
+    """samplerate 0 (ratio inf/NaN: never resets, counter climbs), huge shifts, negative zero."""
+    for shift, rate in [(5000.0, 0), (0.0, 0), (3.0e38, 1), (-0.0, 1024000), (1e-30, 1)]:
+        want, sn_end = oracle_counters(orc, [(5000, shift)], rate, 0)
+        c, w = doppler_amd.plan_simulate([(5000, shift)], rate, 0, 256, 1, 3)
+        assert (w == 1).all() and np.array_equal(c, want), (shift, rate)
+        assert doppler_amd.plan_describe([(5000, shift)], rate, 0)[1] == sn_end
