@@ -65,12 +65,108 @@ def cpu_baseline(x_host, gpu_out_host):
     return out
 
 
+TLE1 = b"1 39161U 13021C   15022.00000000  .00000500  00000-0  80000-4 0  9990"   # synthetic ESTCUBE-1-like set
+TLE2 = b"2 39161  98.1000  95.0000 0010000  90.0000 270.0000 14.69000000 90000"   # (tests/golden/estcube1_synthetic.tle)
+
+
+def track_segments(seconds, rate, in_fmt, start_unix, frequency=437505000, offset=5000):
+    """(n_samples, shift_hz) segments of `doppler track --time` over `seconds` of stream: host SGP4 range rates
+    per whole second -> the reference's per-block schedule (main.rs:156-184) -> runs of equal shift."""
+    import ctypes as C
+    import numpy as np
+    import doppler_amd
+    lib = doppler_amd.lib
+    out = (C.c_double * 4)()
+    rr = np.empty(seconds + 2, dtype=np.float64)
+    for t in range(seconds + 2):
+        assert lib.dpx_orbit_observe(TLE1, TLE2, 58.26541, 26.46667, 76.0, float(start_unix + t), out) == 0
+        rr[t] = out[3]
+    bps = 4 if in_fmt == "i16" else 8
+    nbytes = seconds * rate * bps
+    cap = nbytes // 8192 + 2
+    hz = np.empty(cap, dtype=np.float32)
+    nb = C.c_size_t()
+    assert lib.dpx_track_schedule(rr.ctypes.data, rr.size, rate, frequency, offset, 1, 0 if in_fmt == "i16" else 1,
+                                  nbytes, hz.ctypes.data, cap, C.byref(nb)) == 0
+    hz = hz[: nbytes // 8192]
+    spb = 8192 // bps
+    edges = np.flatnonzero(hz[1:].view(np.uint32) != hz[:-1].view(np.uint32)) + 1
+    starts = np.concatenate([[0], edges])
+    ends = np.concatenate([edges, [hz.size]])
+    return [(int((e - s0) * spb), float(hz[s0])) for s0, e in zip(starts, ends)]
+
+
+def run_track(args, world, rank, dev, ctx):
+    """Secondary workload (BASELINE.json configs[2] at N=1, configs[4] at N>1); never the default."""
+    import calendar
+    from doppler_amd import shard
+    rate = 1024000
+    if world == 1:
+        seconds, it, ot, start = 600, "i16", "i16", calendar.timegm((2015, 1, 22, 19, 48, 0))
+        name = "doppler track -s 1024000 -i i16 (synthetic ESTCUBE-1-like TLE, --time replay of a 10 min overpass, --offset 5000)"
+    else:
+        seconds, it, ot, start = 3600, "f32", "i16", calendar.timegm((2015, 1, 22, 19, 23, 0))
+        name = "doppler track -s 1024000 -i f32 -o i16, 1 h replay sharded in time chunks over %d GPUs, --offset 5000" % world
+    bi, bo = (4 if it == "i16" else 8), (4 if ot == "i16" else 8)
+    segs = track_segments(seconds, rate, it, start)
+    total = seconds * rate
+    lo, hi = shard.chunk_bounds(total, world, rank, bytes_per_sample=bi)
+    before, inside = shard.segments_for_chunk(segs, lo, hi)
+    t0 = time.perf_counter()
+    plan = ctx.plan_segments(inside, rate, samplenum=shard.seed_for_segments(before, rate))
+    plan_ms = (time.perf_counter() - t0) * 1e3
+    n = hi - lo
+    x = (torch.randint(-23170, 23171, (2 * n,), dtype=torch.int16, device=dev) if it == "i16"
+         else torch.rand(2 * n, dtype=torch.float32, device=dev) * 2 - 1)
+    out = torch.empty(n * bo, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        plan.run(x.data_ptr(), it, out.data_ptr(), ot, stream.cuda_stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        plan.run(x.data_ptr(), it, out.data_ptr(), ot, stream.cuda_stream)
+        b.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        kms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        ach = n * (bi + bo) / (kms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "Msamples/s IQ throughput + % HBM roofline (track replay, secondary workload)",
+            "value": round(total * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": name, "samples_total": total, "samples_per_gpu": n, "segments_total": len(segs),
+                       "segments_this_rank": len(inside), "plan_ms": round(plan_ms, 2), "in": it, "out": ot},
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "dpx::tile_kernel",
+                         "avg_launch_ms": round(kms, 4), "algorithmic_bytes_per_launch": n * (bi + bo)},
+        }), flush=True)
+    plan.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--workload", default="const", choices=["const", "track"],
+                    help="const = the headline (default); track = secondary track-replay workload")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,6 +191,12 @@ def main():
     from doppler_amd import shard
 
     ctx = doppler_amd.Context(dev_index)
+    if args.workload == "track":
+        run_track(args, world, rank, dev, ctx)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     n = N_SAMPLES
     # rank r owns global samples [r*n, (r+1)*n) of the world*n-sample stream: block-aligned chunk,
     # counter seeded from the closed form of dsp.rs:125-130

@@ -47,8 +47,8 @@ struct dpx_ctx {
     int device = -1;
     int n_cu = 0;
     bool fma = true;          // libm variant whose sincosf the kernels reproduce
-    int block = 256;          // lanes per workgroup (128 or 256)
-    int vecs = 1;             // 4-sample groups per lane (1 or 2)
+    int block = 128;          // tile kernel: lanes per workgroup (128 or 256)
+    int vecs = 2;             // tile kernel: 4-sample groups per lane (1 or 2); 128 x 2 measured best
     int variant = 0;
     bool use_rows = true;     // false: tile kernel only (measurement A/B)
     hipStream_t stream = nullptr;   // internal stream of the host-pointer entry points
@@ -423,8 +423,8 @@ int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
     if (plan.n_samples != n_samples) return fail(DPX_ERR_PLAN, "segments hold %llu samples, buffers %llu",
                                                  (unsigned long long)plan.n_samples, (unsigned long long)n_samples);
     dpx::LaunchGeom g;
-    g.block = block ? block : 256;
-    g.vecs = vecs ? vecs : 1;
+    g.block = block ? block : 128;
+    g.vecs = vecs ? vecs : 2;
     dpx::finalize(plan, g.tile(), variant != 4);
     memset(writes, 0, n_samples);
     dpx::simulate(plan, counters, writes);

@@ -140,14 +140,16 @@ uint32_t pick_row_length(uint32_t P)
     uint64_t g = P, h = 4;
     while (h) { const uint64_t t = g % h; g = h; h = t; }
     const uint64_t base = (uint64_t)P / g * 4;
-    if (base > kRowsMaxL) return 0;
+    uint64_t max_l = kRowsMaxL;
+    if (const char *e = getenv("DPX_ROWS_MAXL")) max_l = strtoull(e, nullptr, 0);   // measurement override
+    if (base > max_l) return 0;
     if (const char *e = getenv("DPX_ROWS_MULT")) {   // measurement override: L = mult * lcm(P, 4)
         const uint64_t L = base * (uint64_t)atoi(e);
-        return (L >= base && L <= kRowsMaxL) ? (uint32_t)L : 0;
+        return (L >= base && L <= max_l) ? (uint32_t)L : 0;
     }
     uint32_t best = 0;
     double best_score = -1e9;
-    for (uint64_t L = base; L <= kRowsMaxL; L += base) {
+    for (uint64_t L = base; L <= max_l; L += base) {
         double score = (double)L / (256.0 * (double)((L + 255) / 256));
         if (L % 32 != 0) score -= 0.20;
         if (L % 1024 != 0) score -= 0.03;

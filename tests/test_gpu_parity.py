@@ -200,7 +200,7 @@ def test_const_stream_bulk_vs_oracle(ctx, orc, intype, outtype):
             assert fin == sn_w
             assert_same_bytes(got, want, outtype, "variant=%d block=%d vecs=%d" % (variant, block, vecs))
     finally:
-        ctx.set_tuning(256, 1, 3)
+        ctx.set_tuning(128, 2, 3)
 
 
 @pytest.mark.parametrize("shift,rate", [(815000.0, 2400000), (9876.543, 1024000), (-5234.17, 1024000), (3.0, 1024000),
