@@ -13,7 +13,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-f
 LIB := $(LIBDIR)/libdoppler_hip.so
 OBJS := $(LIBDIR)/dpx_kernels.o $(LIBDIR)/dpx_api.o $(LIBDIR)/dpx_planner.o $(LIBDIR)/orbit.o $(LIBDIR)/schedule.o
 
-all: lib cli oracle
+all: lib cli oracle cpptest
 
 lib: $(LIB)
 
@@ -47,6 +47,13 @@ $(BINDIR)/doppler: $(CSRC)/cli/main.cpp $(CSRC)/cli/args.cpp $(CSRC)/cli/args.h 
 	$(HIPCC) -O2 -std=c++17 -ffp-contract=off -Wall -Iinclude -x hip --offload-arch=$(ARCH) $(CSRC)/cli/main.cpp $(CSRC)/cli/args.cpp \
 	    -o $@ -L$(LIBDIR) -ldoppler_hip -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,$(ROCM)/lib
 
+# the reference's in-file tests against the C++ mirror of doppler::dsp (needs the oracle as checker)
+tests/cpp/test_dsp: tests/cpp/test_dsp.cpp include/doppler_dsp.hpp include/doppler_hip.h $(LIB) oracle
+	g++ -O2 -std=c++17 -ffp-contract=off -Wall -o $@ tests/cpp/test_dsp.cpp -L$(LIBDIR) -ldoppler_hip -Loracle -loracle \
+	    -Wl,-rpath,'$$ORIGIN/../../doppler_amd/lib' -Wl,-rpath,'$$ORIGIN/../../oracle' -Wl,-rpath,$(ROCM)/lib -lm
+
+cpptest: tests/cpp/test_dsp
+
 oracle:
 	$(MAKE) -C oracle all
 
@@ -54,4 +61,4 @@ clean:
 	rm -rf $(LIBDIR) $(BINDIR)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib cli oracle clean
+.PHONY: all lib cli oracle cpptest clean
