@@ -29,7 +29,7 @@ SHIFT = 5000
 RATE = 1024000
 BYTES_PER_SAMPLE = 8           # algorithmic: 4 read + 4 written
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
-CPU_SAMPLE = 1 << 27           # cpu_baseline: first 512 MiB of the same stream (about 10 s on one core)
+CPU_SAMPLE = N_SAMPLES         # cpu_baseline: the whole 1 GiB stream (about 10 s on one core)
 
 
 def cpu_baseline(x_host, gpu_out_host):
