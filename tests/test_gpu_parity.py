@@ -306,3 +306,30 @@ def test_special_values_and_degenerate_ratios(ctx, orc):
         o, _ = orc.shift_frequency(cx, 0, shift, rate)
         got, _, _ = dsp.shift_block(xi, "i16", "i16", 0, shift, rate, ctx=ctx)
         assert_same_bytes(got, orc.pack_i16(o), "i16", "i16 corners (saturating cast)")
+
+
+def test_random_cases_against_oracle(ctx, orc):
+    """Seeded random sweep through the bulk path: formats, arbitrary f32 shifts, rates, counter starts, 1-4 segments."""
+    rng = np.random.default_rng(77)
+    for case in range(60):
+        rate = int(rng.choice([8000, 48000, 256000, 1024000, 2400000, 1000003]))
+        intype, outtype = [("i16", "i16"), ("f32", "f32"), ("i16", "f32"), ("f32", "i16")][case % 4]
+        segs = []
+        for _ in range(int(rng.integers(1, 5))):
+            hz = float(np.float32(rng.uniform(-15000, 15000))) if rng.random() < 0.6 else float(np.float32(rng.integers(-9999, 9999)))
+            cnt = int(rng.integers(1, 5000)) if rng.random() < 0.5 else int(rng.integers(66000, 200000))
+            segs.append((cnt, hz))
+        sn0 = int(rng.choice([0, 1, 77, 4096]))
+        n = sum(c for c, _ in segs)
+        x = make_iq(intype, n, 500 + case, full_scale=True)
+        cx = orc.convert_iqi16_to_complex(x) if intype == "i16" else orc.convert_iqf32_to_complex(x)
+        outs, sn, pos = [], sn0, 0
+        for cnt, hz in segs:
+            o, sn = orc.shift_frequency(cx[pos:pos + cnt], sn, hz, rate)
+            outs.append(o)
+            pos += cnt
+        o = np.concatenate(outs)
+        want = orc.pack_i16(o) if outtype == "i16" else orc.pack_f32(o)
+        got, fin = run_bulk(ctx, x, intype, outtype, segs, rate, sn0=sn0)
+        assert fin == sn, (case, segs)
+        assert_same_bytes(got, want, outtype, "random case %d %r" % (case, segs))

@@ -138,3 +138,32 @@ def test_degenerate_ratios(orc):
         c, w = doppler_amd.plan_simulate([(5000, shift)], rate, 0, 256, 1, 3)
         assert (w == 1).all() and np.array_equal(c, want), (shift, rate)
         assert doppler_amd.plan_describe([(5000, shift)], rate, 0)[1] == sn_end
+
+
+def test_random_plans_against_sequential_rule(orc):
+    """Seeded random sweep: arbitrary f32 shifts (as track mode produces), rates, counter starts, multi-segment
+    plans — the launch lists must reproduce the sequential counter sample for sample."""
+    rng = np.random.default_rng(2024)
+    for case in range(120):
+        rate = int(rng.choice([8000, 48000, 256000, 1024000, 2400000, 300000, 1000003]))
+        nseg = int(rng.integers(1, 5))
+        segs = []
+        for _ in range(nseg):
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                hz = float(np.float32(rng.integers(-20000, 20000)))
+            elif kind == 1:
+                hz = float(np.float32(rng.uniform(-12000, 12000)))
+            elif kind == 2:
+                hz = float(np.float32(rate / float(rng.choice([2, 3, 4, 5, 8, 10, 16, 100, 1000]))))
+            else:
+                hz = float(np.float32(rng.uniform(-3, 3)))
+            segs.append((int(rng.integers(1, 9000)) if rng.random() < 0.7 else int(rng.integers(60000, 90000)), hz))
+        sn0 = int(rng.choice([0, 1, 2, 1000, 65535, 1 << 20]))
+        want, sn_end = oracle_counters(orc, segs, rate, sn0)
+        variant = int(rng.choice([3, 4, 1, 2]))
+        block, vecs = [(256, 1), (128, 2), (128, 1), (256, 2)][case % 4]
+        c, w = doppler_amd.plan_simulate(segs, rate, sn0, block, vecs, variant)
+        assert (w == 1).all(), (case, segs, rate, sn0, variant)
+        assert np.array_equal(c, want), (case, segs, rate, sn0, variant, int(np.flatnonzero(c != want)[0]))
+        assert doppler_amd.plan_describe(segs, rate, sn0)[1] == sn_end
