@@ -179,6 +179,7 @@ int run_host(dpx_ctx *ctx, const void *in, size_t n, int in_fmt, void *out, int 
     }
     const dpx::LaunchGeom g = geometry(ctx);
     dpx::finalize(plan, g.tile(), ctx->use_rows);
+    if (plan.error) return fail(DPX_ERR_PLAN, "%s", plan.error);
     const size_t in_bytes = n * bytes_per_sample(in_fmt), out_bytes = n * bytes_per_sample(out_fmt);
     int rc = ensure_stage(ctx, in_bytes, out_bytes);
     if (rc != DPX_OK) return rc;
@@ -513,6 +514,7 @@ int dpx_plan_segments(dpx_ctx *ctx, const dpx_segment *segs, size_t n_segs, uint
     dpx::finalize(p->host, p->geom.tile(), ctx->use_rows);
     hipError_t e = hipSetDevice(ctx->device);
     int rc = e == hipSuccess ? DPX_OK : fail(DPX_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    if (rc == DPX_OK && p->host.error) rc = fail(DPX_ERR_PLAN, "%s", p->host.error);
     if (rc == DPX_OK && p->host.n_samples) {
         rc = materialize(ctx, p->host, p->dev, p->fma, ctx->stream);
         if (rc == DPX_OK) {

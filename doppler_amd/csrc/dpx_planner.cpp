@@ -166,6 +166,7 @@ struct Interval { uint64_t lo, hi; };
 void finalize(PlanResult &plan, uint32_t tile, bool use_rows)
 {
     plan.tile = tile;
+    plan.error = nullptr;
     plan.tables.clear();
     plan.launches.clear();
     const size_t ns = plan.segs.size();
@@ -254,6 +255,8 @@ void finalize(PlanResult &plan, uint32_t tile, bool use_rows)
         pool += ((uint64_t)P + tile + 3) & ~3ull;
     }
     plan.lut_entries = pool;
+    if (pool > 0xffffffffull) plan.error = "corrector tables exceed 2^32 entries";
+    if ((plan.n_samples + tile - 1) / tile > 0xffffffffull) plan.error = "stream longer than 2^32 tiles";
 
     // ---- everything no rows launch covers goes to tile-kernel launches
     std::sort(covered.begin(), covered.end(), [](const Interval &a, const Interval &b) { return a.lo < b.lo; });

@@ -46,6 +46,7 @@ struct PlanResult {
     std::vector<uint32_t> hint;      // stretch index per 2^kHintShift samples
     std::vector<TableBuild> tables;
     std::vector<Launch> launches;
+    const char *error = nullptr;     // set by finalize() when the plan cannot be laid out
 };
 
 // variant: 0 auto, 1 sincos per sample wherever the period allows (>= 4), 2 tables whenever they fit

@@ -333,3 +333,45 @@ def test_random_cases_against_oracle(ctx, orc):
         got, fin = run_bulk(ctx, x, intype, outtype, segs, rate, sn0=sn0)
         assert fin == sn, (case, segs)
         assert_same_bytes(got, want, outtype, "random case %d %r" % (case, segs))
+
+
+def test_c_abi_error_paths(ctx):
+    """Bad arguments come back as error codes with a message, never as a crash or a silent fallback."""
+    import ctypes as C
+    import doppler_amd
+    from doppler_amd import _lib
+    lib = doppler_amd.lib
+    h = ctx.handle
+    sn = C.c_uint32(0)
+    n = C.c_size_t(0)
+    buf = np.zeros(64, dtype=np.uint8)
+    assert lib.dpx_shift_block(h, buf.ctypes.data, 64, 7, buf.ctypes.data, 64, 0, C.byref(sn), 1.0, 1000, C.byref(n)) == _lib.ERR_ARG
+    assert lib.dpx_shift_block(h, buf.ctypes.data, 64, 0, buf.ctypes.data, 16, 1, C.byref(sn), 1.0, 1000, C.byref(n)) == _lib.ERR_CAPACITY
+    assert lib.dpx_shift_block(h, buf.ctypes.data, 62, 0, buf.ctypes.data, 64, 0, C.byref(sn), 1.0, 1000, C.byref(n)) == _lib.ERR_BLOCK_LEN
+    assert b"whole number" in lib.dpx_last_error()
+    assert lib.dpx_shift_block(None, buf.ctypes.data, 64, 0, buf.ctypes.data, 64, 0, C.byref(sn), 1.0, 1000, C.byref(n)) == _lib.ERR_ARG
+    plan = ctx.plan_const(5000.0, 1024000, 4096)
+    d = ctx.malloc(65536)
+    try:
+        with pytest.raises(doppler_amd.DspError) as e:
+            plan.run(d + 4, "i16", d + 32768, "i16")           # misaligned device pointer
+        assert e.value.code == _lib.ERR_ARG
+        with pytest.raises(doppler_amd.DspError):
+            plan.run(0, "i16", d, "i16")
+        with pytest.raises(doppler_amd.DspError):
+            plan.run(d, "u8", d + 32768, "i16")
+        plan.run(d, "i16", d + 32768, "i16")                  # and the valid call still works afterwards
+        ctx.synchronize()
+    finally:
+        ctx.free(d)
+        plan.close()
+    with pytest.raises(doppler_amd.DspError):
+        ctx.set_tuning(100, 1, 3)
+    empty = ctx.plan_const(5000.0, 1024000, 0)                # empty plans are legal and run as no-ops
+    assert empty.n_samples == 0 and empty.final_samplenum == 0
+    empty.run(0, "i16", 0, "i16")
+    empty.close()
+    assert lib.dpx_device_count(C.byref(C.c_int())) == 0
+    with pytest.raises(doppler_amd.DspError) as e:
+        doppler_amd.Context(99)
+    assert e.value.code == _lib.ERR_NO_DEVICE
