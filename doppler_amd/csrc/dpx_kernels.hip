@@ -168,7 +168,7 @@ __device__ __forceinline__ void one_sample(const uint8_t *in, uint8_t *out, cons
     store_one<OUT_FMT>(out, g, re, im);
 }
 
-// ---- rows kernel: one wavefront, kRowsR rows of one tabulated periodic stretch
+// ---- rows kernel: one wavefront, R rows of one tabulated periodic stretch
 // S samples per lane per row: the wider of the two sides moves as one 16-byte vector per lane,
 // the narrower side as 16 or 8 bytes (measured: 8-byte accesses on the narrow side are free,
 // two 16-byte stores at a 32-byte lane stride halve the rate).
@@ -179,7 +179,7 @@ template <int IN_FMT, int OUT_FMT> struct RowVec {
 // Argument order matters: the first 16 dwords are preloaded into SGPRs at wavefront
 // launch (-amdgpu-kernarg-preload-count=16), and they are exactly what the matrix
 // path needs — a one-shot wavefront issues its loads without waiting for any s_load.
-template <int IN_FMT, int OUT_FMT, bool FMA>
+template <int IN_FMT, int OUT_FMT, bool FMA, int R>
 __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restrict__ in,
                                                           uint8_t *__restrict__ out,
                                                           const float2 *__restrict__ tab,   // table, origin = sample A
@@ -191,7 +191,6 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
                                                           RowsArgs ra)
 {
     constexpr int S = RowVec<IN_FMT, OUT_FMT>::S;
-    constexpr int R = kRowsR;
     constexpr int IB = Fmt<IN_FMT>::kBytes, OB = Fmt<OUT_FMT>::kBytes;
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
 
@@ -483,9 +482,15 @@ static int rows_t(const void *d_in, void *d_out, const DevSeg *d_segs, const voi
     const uint64_t M = ((1ull << sh) + cols - 1) / cols;
     const dim3 grid((uint32_t)(n_main + n_extra));
     const float2 *tab = lut + r.tab_off;
-    if (fma) rows_kernel<IN_FMT, OUT_FMT, true><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_main, d_segs, r);
-    else     rows_kernel<IN_FMT, OUT_FMT, false><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_main, d_segs, r);
-    return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;
+#define DPX_ROWS_CASE(RR)                                                                                                                   \
+    if (r.R == RR) {                                                                                                                        \
+        if (fma) rows_kernel<IN_FMT, OUT_FMT, true, RR><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_main, d_segs, r);  \
+        else     rows_kernel<IN_FMT, OUT_FMT, false, RR><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_main, d_segs, r); \
+        return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                                                      \
+    }
+    DPX_ROWS_CASE(2) DPX_ROWS_CASE(4) DPX_ROWS_CASE(8)
+#undef DPX_ROWS_CASE
+    return DPX_ERR_ARG;
 }
 
 int launch_rows(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,

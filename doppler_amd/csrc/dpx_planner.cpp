@@ -190,13 +190,20 @@ void finalize(PlanResult &plan, uint32_t tile, bool use_rows)
         // matrix origin on a 256-sample boundary: 1 KiB of i16 / 2 KiB of f32 per wavefront, aligned
         const uint64_t A = (s.first + 255) & ~255ull;
         if (A >= end) continue;
-        const uint64_t n_rg = (end - A) / ((uint64_t)kRowsR * L);
+        // rows per wavefront: 2 while the table stays L1/L2-hot, 4 once it is large (measured, i16, GB/s at
+        // R = 2 / 4 / 8:  L = 1024: 6615 / 6264 / 6194;  L = 82 944: 6085 / 6243 / 6152;  L = 112 172: 5406 / 5660 / 5777)
+        uint32_t R = L <= 16384 ? 2 : 4;
+        if (const char *e = getenv("DPX_ROWS_R")) R = (uint32_t)atoi(e);   // measurement override
+        if (R != 2 && R != 4 && R != 8) R = 2;
+        const uint64_t n_rg = (end - A) / ((uint64_t)R * L);
         if (n_rg < 16) continue;
         s.flags |= kSegRows | kSegOwnsTable;
         Launch ln;
         ln.kind = 0;
         ln.rows.A = A;
-        ln.rows.B = A + n_rg * kRowsR * L;
+        ln.rows.B = A + n_rg * R * L;
+        ln.rows.R = R;
+        ln.rows.pad = 0;
         ln.rows.n_rg = n_rg;
         ln.rows.L = L;
         ln.rows.r0 = s.first;
@@ -308,9 +315,9 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
             const TableBuild *tb = nullptr;
             for (const TableBuild &t : plan.tables) if (t.off == r.tab_off) tb = &t;
             for (uint64_t rg = 0; rg < r.n_rg; ++rg)
-                for (int row = 0; row < kRowsR; ++row)
+                for (uint32_t row = 0; row < r.R; ++row)
                     for (uint32_t cs = 0; cs < r.L; ++cs) {
-                        const uint64_t g = r.A + (rg * kRowsR + row) * (uint64_t)r.L + cs;
+                        const uint64_t g = r.A + (rg * r.R + row) * (uint64_t)r.L + cs;
                         put(g, (uint32_t)(((uint64_t)(tb->n_first - 1u) + cs) % tb->period) + 1u);
                     }
             for (uint64_t g = r.r0; g < r.A; ++g) generic(r.seg_lo, g);

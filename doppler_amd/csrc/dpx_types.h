@@ -46,7 +46,6 @@ constexpr uint32_t kLutMaxEntries = 4194304; // longest tile-kernel table (32 Mi
 constexpr uint32_t kRowsMaxL = 131072;      // longest rows-kernel row / table (1 MiB)
 constexpr int kHintShift = 16;              // one stretch hint per 65536 samples
 constexpr int kRowsLanes = 64;              // rows kernel: one wavefront per workgroup
-constexpr int kRowsR = 2;                   // rows per workgroup (share one set of correctors)
 
 // tile-kernel geometry
 struct LaunchGeom {
@@ -57,20 +56,22 @@ struct LaunchGeom {
 
 // One rows-kernel launch: a tabulated periodic stretch processed as a matrix whose
 // rows are L samples long (L a multiple of the period and of 4), so that a column
-// always sees the same corrector.  A workgroup (one wavefront) takes kRowsR
+// always sees the same corrector.  A workgroup (one wavefront) takes R (2, 4 or 8)
 // consecutive rows x 64 lanes x S samples; column slices of one row group are
 // consecutive workgroups, so the grid sweeps HBM contiguously.
 // Workgroups past n_rg * cols evaluate the ragged ranges [r0, A) and [B, r1)
 // sample by sample (generic stretch lookup, sincos per sample).
 struct RowsArgs {
     uint64_t A;          // first sample of the matrix (multiple of 256)
-    uint64_t B;          // one past its last sample: A + n_rg * kRowsR * L
+    uint64_t B;          // one past its last sample: A + n_rg * R * L
     uint64_t r0, r1;     // ragged ranges [r0, A) and [B, r1) handled by the extra workgroups
     uint64_t n_rg;       // row groups
     uint32_t L;          // row length in samples
     uint32_t tab_off;    // table-pool entry index of the L-entry table (origin: sample A)
     uint32_t seg_lo;     // index of the stretch holding r0
     uint32_t n_segs;
+    uint32_t R;          // rows per workgroup: 2, 4 or 8
+    uint32_t pad;
 };
 
 struct TileArgs {
