@@ -357,6 +357,21 @@ int dpx_pack_iqi16(dpx_ctx *ctx, const dpx_complex32 *inbuf, size_t n, uint8_t *
     return DPX_OK;
 }
 
+int dpx_ccexpf(dpx_ctx *ctx, dpx_complex32 *z, size_t n)
+{
+    if (!ctx || (n && !z)) return fail(DPX_ERR_ARG, "bad argument");
+    if (n == 0) return DPX_OK;
+    DPX_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_stage(ctx, n * 8, 0);
+    if (rc != DPX_OK) return rc;
+    DPX_HIP(hipMemcpyAsync(ctx->stage_in, z, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = dpx::launch_ccexpf(ctx->stage_in, n, ctx->fma, ctx->stream);
+    if (rc != DPX_OK) return fail(rc, "kernel launch failed");
+    DPX_HIP(hipMemcpyAsync(z, ctx->stage_in, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    DPX_HIP(hipStreamSynchronize(ctx->stream));
+    return DPX_OK;
+}
+
 int dpx_ccexpf_imag(dpx_ctx *ctx, dpx_complex32 *z, size_t n)
 {
     if (!ctx || (n && !z)) return fail(DPX_ERR_ARG, "bad argument");

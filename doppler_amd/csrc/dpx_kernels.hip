@@ -420,6 +420,17 @@ __global__ __launch_bounds__(kBlock) void ccexpf_imag_kernel(float2 *__restrict_
     }
 }
 
+// complex.c:33-39 for any argument: z <- cexpf(z.re + i*z.im)
+template <bool FMA>
+__global__ __launch_bounds__(kBlock) void ccexpf_kernel(float2 *__restrict__ z, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+        float re, im;
+        ccexpf_glibc<FMA>(z[i].x, z[i].y, re, im);
+        z[i] = make_float2(re, im);
+    }
+}
+
 // ------------------------------------------------------------ launch wrappers
 
 #define DPX_DISPATCH_FMT(FN, ...)                                                                           \
@@ -539,6 +550,14 @@ int launch_pack_i16(const void *d_in, void *d_out, uint64_t n, void *stream)
 {
     pack_i16_kernel<<<aux_grid(n), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
         static_cast<const float2 *>(d_in), static_cast<uint32_t *>(d_out), n);
+    return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;
+}
+
+int launch_ccexpf(void *d_z, uint64_t n, bool fma, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (fma) ccexpf_kernel<true><<<aux_grid(n), kBlock, 0, st>>>(static_cast<float2 *>(d_z), n);
+    else     ccexpf_kernel<false><<<aux_grid(n), kBlock, 0, st>>>(static_cast<float2 *>(d_z), n);
     return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;
 }
 

@@ -126,6 +126,115 @@ __device__ __forceinline__ void sincosf_glibc(float y, float &sn, float &cs)
     cs = rc;
 }
 
+// 2^(i/32) as IEEE-754 doubles (glibc __exp2f_data.tab)
+__device__ __constant__ const uint64_t kExp2fTab[32] = {
+    0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b,
+    0x3fef54873168b9aa, 0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb,
+    0x3feedea64c123422, 0x3feece086061892d, 0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429,
+    0x3feea47eb03a5585, 0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74, 0x3feea11473eb0187, 0x3feea589994cce13,
+    0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d, 0x3feee89f995ad3ad,
+    0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f,
+    0x3fefa4afa2a490da, 0x3fefd0765b6e4540,
+};
+
+// expf, bit-identical to glibc 2.35 (optimized-routines expf: x*32/ln2 = k + r, 2^(k/32) from the
+// table, cubic in r, all in double).  Not on the streaming path: ccexpf arguments with a real
+// part only (reference src/dsp.rs:57-83).
+template <bool FMA>
+__device__ __forceinline__ float expf_glibc(float x)
+{
+    constexpr double SHIFT = 0x1.8p+52, INVLN2N = 0x1.71547652b82fep+5;
+    constexpr double C0 = 0x1.c6af84b912394p-20, C1 = 0x1.ebfce50fac4f3p-13, C2 = 0x1.62e42ff0c52d6p-6;
+    const uint32_t xi = __float_as_uint(x);
+    const uint32_t abstop = (xi >> 20) & 0x7ffu;
+    if (abstop >= 0x42bu) {                       // |x| >= 88 or nan
+        if (xi == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8u) return x + x;
+        if (x > 0x1.62e42ep6f) return __uint_as_float(0x7f800000u);    // 0x1p97f * 0x1p97f
+        if (x < -0x1.9fe368p6f) return 0.0f;                           // 0x1p-95f * 0x1p-95f
+        if (x < -0x1.9d1d9ep6f) return __uint_as_float(1u);            // 0x1.4p-75f squared rounds to 2^-149
+    }
+    const double xd = (double)x;
+    double kd, r;
+    if constexpr (FMA) {
+        kd = __builtin_fma(INVLN2N, xd, SHIFT);
+    } else {
+        const double z = INVLN2N * xd;
+        kd = z + SHIFT;
+    }
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd -= SHIFT;
+    if constexpr (FMA) {
+        r = __builtin_fma(INVLN2N, xd, -kd);
+    } else {
+        const double z = INVLN2N * xd;
+        r = z - kd;
+    }
+    const uint64_t t = kExp2fTab[ki & 31u] + (ki << 47);
+    const double sc = __longlong_as_double((long long)t);
+    const double z2 = mad<FMA>(C0, r, C1);
+    const double r2 = r * r;
+    double y = mad<FMA>(C2, r, 1.0);
+    y = mad<FMA>(z2, r2, y);
+    y = y * sc;
+    return (float)y;
+}
+
+// ccexpf of reference src/complex.c:33-39 for ANY argument: the argument construction
+// `real + imag * I` followed by glibc 2.35 cexpf (math/s_cexp_template.c), on the two functions above.
+template <bool FMA>
+__device__ __forceinline__ void ccexpf_glibc(float re, float im, float &out_re, float &out_im)
+{
+    const float FLT_MIN_ = 1.17549435e-38f, FLT_MAX_ = 3.40282347e+38f;
+    const float inf = __uint_as_float(0x7f800000u), nan = __uint_as_float(0x7fc00000u);
+    float xr = __fadd_rn(re, __fmul_rn(im, 0.0f));
+    const float xi = im;
+    const bool r_fin = fabsf(xr) <= FLT_MAX_, i_fin = fabsf(xi) <= FLT_MAX_;     // false for inf and nan
+    float sinix = xi, cosix = 1.0f;
+    if (i_fin && fabsf(xi) > FLT_MIN_) sincosf_glibc<FMA>(xi, sinix, cosix);
+    if (r_fin) {
+        if (!i_fin) { out_re = out_im = nan; return; }
+        const float t = 88.0f;
+        if (xr > t) {
+            const float exp_t = expf_glibc<FMA>(t);
+            xr = __fsub_rn(xr, t);
+            sinix = __fmul_rn(sinix, exp_t);
+            cosix = __fmul_rn(cosix, exp_t);
+            if (xr > t) {
+                xr = __fsub_rn(xr, t);
+                sinix = __fmul_rn(sinix, exp_t);
+                cosix = __fmul_rn(cosix, exp_t);
+            }
+        }
+        if (xr > t) {
+            out_re = __fmul_rn(FLT_MAX_, cosix);
+            out_im = __fmul_rn(FLT_MAX_, sinix);
+        } else {
+            const float e = expf_glibc<FMA>(xr);
+            out_re = __fmul_rn(e, cosix);
+            out_im = __fmul_rn(e, sinix);
+        }
+    } else if (xr != xr) {                       // real part NaN
+        out_re = nan;
+        out_im = (xi == 0.0f) ? xi : nan;
+    } else if (i_fin) {                          // real part +-inf, imaginary finite
+        const float value = (__float_as_uint(xr) >> 31) ? 0.0f : inf;
+        if (xi == 0.0f) {
+            out_re = value;
+            out_im = xi;
+        } else {
+            out_re = copysignf(value, cosix);
+            out_im = copysignf(value, sinix);
+        }
+    } else if (!(__float_as_uint(xr) >> 31)) {   // +inf, imaginary inf/nan
+        out_re = inf;
+        out_im = xi - xi;
+    } else {                                     // -inf, imaginary inf/nan
+        out_re = 0.0f;
+        out_im = copysignf(0.0f, xi);
+    }
+}
+
 // The corrector of dsp.rs:121-122 for counter value n:
 //   theta = (-2*PI) * (ratio * (n as f32))   — each product rounded to f32,
 //   (c, s) = cexpf(0 + i*theta) = (cosf(theta), sinf(theta)).

@@ -92,5 +92,6 @@ int launch_copy(const void *d_in, void *d_out, uint64_t n_bytes, void *stream);
 int launch_unpack_i16(const void *d_in, void *d_out, uint64_t n_samples, void *stream);
 int launch_pack_i16(const void *d_in, void *d_out, uint64_t n_samples, void *stream);
 int launch_ccexpf_imag(void *d_z, uint64_t n, bool fma, void *stream);
+int launch_ccexpf(void *d_z, uint64_t n, bool fma, void *stream);
 
 }  // namespace dpx

@@ -7,7 +7,7 @@ through the C ABI (include/doppler_hip.h) to the HIP kernels — nothing is comp
     convert_iqf32_to_complex(inbuf)                       src/dsp.rs:101-115
     shift_frequency(inbuf, samplenum, shift_hz, samplerate)   src/dsp.rs:117-134
     shift_block(...)                                      body of the `shift` closure, src/main.rs:62-99
-    ccexpf(z)                                             src/complex.c:33-39 (imaginary arguments)
+    ccexpf(z)                                             src/complex.c:33-39
 
 Rust's `&mut u32` samplenum becomes an extra return value.
 Where the reference panics on a ragged byte length (`assert!`, dsp.rs:87/103) these raise
@@ -84,8 +84,8 @@ def shift_block(inbytes, intype, outtype, samplenum, shift_hz, samplerate, ctx=N
 
 
 def ccexpf(z, ctx=None):
-    """cexpf(0 + i*z.im) for each element (the only argument shape dsp.rs:121 builds)."""
+    """src/complex.c:33-39: cexpf(z.re + i*z.im) for each element (returned; the C function works in place)."""
     ctx = _ctx(ctx)
     a = np.array(z, dtype=complex32, copy=True).reshape(-1)
-    check(ctx._lib.dpx_ccexpf_imag(ctx.handle, a.ctypes.data, a.size))
+    check(ctx._lib.dpx_ccexpf(ctx.handle, a.ctypes.data, a.size))
     return a

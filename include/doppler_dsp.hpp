@@ -79,12 +79,10 @@ inline std::vector<Complex32> shift_frequency(const std::vector<Complex32> &inbu
     return out;
 }
 
-// ccexpf for the argument shape the path builds (dsp.rs:121: real part 0): z <- cexpf(0 + i*z.imag).
-// A nonzero real part is outside this library's path and throws.
+// dsp.rs:40-42 / complex.c:33-39: z <- cexpf(z), in place, returns nothing.
 inline void ccexpf(Complex32 *z)
 {
-    if (z->real() != 0.0f) throw Error("ccexpf: only purely imaginary arguments are on the accelerated path");
-    detail::check(dpx_ccexpf_imag(detail::context(), reinterpret_cast<dpx_complex32 *>(z), 1));
+    detail::check(dpx_ccexpf(detail::context(), reinterpret_cast<dpx_complex32 *>(z), 1));
 }
 
 // the fused body of the `shift` closure (main.rs:65-94): returns the packed output bytes

@@ -97,8 +97,12 @@ int dpx_shift_block(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt,
                     void *out, size_t out_cap, int out_fmt, uint32_t *samplenum,
                     float shift_hz, uint32_t samplerate, size_t *n_samples_out);
 
-/* replaces complex.c:33-39 ccexpf for the only argument shape the path ever
- * builds (dsp.rs:121: real part 0): z[k] <- cexpf(0 + i*z[k].im), in place. */
+/* replaces complex.c:33-39 ccexpf(z): z[k] <- cexpf(z[k].re + i*z[k].im), in place, any argument
+ * (bit-identical to glibc 2.35 cexpf, incl. the overflow / inf / nan rules of s_cexp_template.c). */
+int dpx_ccexpf(dpx_ctx *ctx, dpx_complex32 *z, size_t n);
+
+/* the same for the only argument shape the hot path ever builds (dsp.rs:121: real part 0):
+ * z[k] <- cexpf(0 + i*z[k].im); z[k].re is ignored. */
 int dpx_ccexpf_imag(dpx_ctx *ctx, dpx_complex32 *z, size_t n);
 
 /* ------------------------------------------------- host-side counter algebra

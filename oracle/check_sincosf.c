@@ -8,6 +8,7 @@
  *   check_sincosf --stride K     every K-th pattern (quick mode for pytest)
  * Also checks libm cexpf(0+i*theta) == orc_cexpf_imag_glibc235 on the same
  * patterns when --cexp is given.  NaN results compare equal to any NaN.
+ * --expf additionally checks orc_expf_glibc235 against libm expf on the same patterns.
  * Exit status 0 iff the variant reported by orc_detect_libm_variant() has
  * zero mismatches.
  */
@@ -24,7 +25,8 @@
 
 typedef struct {
     uint64_t start, count, stride;
-    int do_cexp;
+    int do_cexp, do_expf;
+    uint64_t mism_expf[2];
     uint64_t mism[2];
     uint64_t mism_cexp[2];
     uint32_t first_bad[2];
@@ -40,6 +42,11 @@ static void *worker(void *arg)
         uint32_t u = (uint32_t)(j->start + k);
         float y, ls, lc;
         memcpy(&y, &u, 4);
+        if (j->do_expf) {
+            const float le = expf(y);
+            for (int v = 0; v < 2; ++v)
+                if (!same(orc_expf_glibc235(y, v), le)) j->mism_expf[v]++;
+        }
         sincosf(y, &ls, &lc);
         float complex z = 0;
         if (j->do_cexp) z = cexpf(0.0f + y * I);
@@ -63,11 +70,12 @@ static void *worker(void *arg)
 int main(int argc, char **argv)
 {
     uint64_t start = 0, count = 1ULL << 32, stride = 1;
-    int do_cexp = 0, nthreads = 8, pos = 0;
+    int do_cexp = 0, do_expf = 0, nthreads = 8, pos = 0;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--stride") && i + 1 < argc) stride = strtoull(argv[++i], 0, 0);
         else if (!strcmp(argv[i], "--threads") && i + 1 < argc) nthreads = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--cexp")) do_cexp = 1;
+        else if (!strcmp(argv[i], "--expf")) do_expf = 1;
         else if (pos == 0) { start = strtoull(argv[i], 0, 0); pos++; }
         else if (pos == 1) { count = strtoull(argv[i], 0, 0); pos++; }
     }
@@ -83,9 +91,10 @@ int main(int argc, char **argv)
         jobs[t].count = (per * t >= count) ? 0 : (per * (t + 1) > count ? count - per * t : per);
         jobs[t].stride = stride;
         jobs[t].do_cexp = do_cexp;
+        jobs[t].do_expf = do_expf;
         pthread_create(&th[t], NULL, worker, &jobs[t]);
     }
-    uint64_t mism[2] = {0, 0}, mc[2] = {0, 0};
+    uint64_t mism[2] = {0, 0}, mc[2] = {0, 0}, me[2] = {0, 0};
     uint32_t fb[2] = {0, 0};
     for (int t = 0; t < nthreads; ++t) {
         pthread_join(th[t], NULL);
@@ -93,16 +102,17 @@ int main(int argc, char **argv)
             if (jobs[t].mism[v] && !mism[v]) fb[v] = jobs[t].first_bad[v];
             mism[v] += jobs[t].mism[v];
             mc[v] += jobs[t].mism_cexp[v];
+            me[v] += jobs[t].mism_expf[v];
         }
     }
     int variant = orc_detect_libm_variant();
     printf("{\"start\": %llu, \"count\": %llu, \"stride\": %llu, \"libm_variant\": %d, "
            "\"mismatch_sse2\": %llu, \"mismatch_fma\": %llu, \"first_bad_sse2\": \"0x%08x\", "
            "\"first_bad_fma\": \"0x%08x\", \"cexp_checked\": %d, \"cexp_mismatch_sse2\": %llu, "
-           "\"cexp_mismatch_fma\": %llu}\n",
+           "\"cexp_mismatch_fma\": %llu, \"expf_checked\": %d, \"expf_mismatch_sse2\": %llu, \"expf_mismatch_fma\": %llu}\n",
            (unsigned long long)start, (unsigned long long)count, (unsigned long long)stride, variant,
            (unsigned long long)mism[0], (unsigned long long)mism[1], fb[0], fb[1], do_cexp,
-           (unsigned long long)mc[0], (unsigned long long)mc[1]);
+           (unsigned long long)mc[0], (unsigned long long)mc[1], do_expf, (unsigned long long)me[0], (unsigned long long)me[1]);
     if (variant < 0) return 2;
-    return (mism[variant] == 0 && mc[variant] == 0) ? 0 : 1;
+    return (mism[variant] == 0 && mc[variant] == 0 && me[variant] == 0) ? 0 : 1;
 }

@@ -46,6 +46,18 @@ void orc_ccexpf_imag_array(const float *theta, size_t n, orc_complex *out, int m
     }
 }
 
+void orc_ccexpf_array(const orc_complex *z, size_t n, orc_complex *out, int mode)
+{
+    for (size_t k = 0; k < n; ++k) {
+        if (mode == 0) {
+            out[k] = z[k];
+            g_ccexpf(&out[k]);
+        } else {
+            orc_ccexpf_glibc235(z[k].re, z[k].im, &out[k].re, &out[k].im, mode == 1);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ A1 ---- */
 /* dsp.rs:85-99: assert len%4==0; per 4 bytes b:
  *   i = ((b[1] as i16) << 8 | b[0] as i16) as f32 / 32768.   (same for q) */

@@ -56,6 +56,10 @@ int orc_get_corrector_mode(void);
  * (same meaning as orc_set_corrector_mode; mode 0 goes through the ccexpf pointer) */
 void orc_ccexpf_imag_array(const float *theta, size_t n, orc_complex *out, int mode);
 
+/* general ccexpf for an array of arguments (any real part): mode 0 through the ccexpf pointer
+ * (libm / reference complex.c), 1 / 2 the restated glibc cexpf (FMA / SSE2 builds of expf and sincosf) */
+void orc_ccexpf_array(const orc_complex *z, size_t n, orc_complex *out, int mode);
+
 /* ---- A1/A2: dsp.rs:85-99, 101-115 ---------------------------------------- */
 /* return number of complex samples written, or ORC_ERR_BLOCK_LEN */
 long orc_convert_iqi16_to_complex(const uint8_t *inbuf, size_t len, orc_complex *out);

@@ -63,6 +63,10 @@ def _load():
     lib.orc_get_corrector_mode.restype = C.c_int
     lib.orc_ccexpf_imag_array.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
     lib.orc_ccexpf_imag_array.restype = None
+    lib.orc_ccexpf_array.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+    lib.orc_ccexpf_array.restype = None
+    lib.orc_expf_glibc235.argtypes = [C.c_float, C.c_int]
+    lib.orc_expf_glibc235.restype = C.c_float
     lib.orc_sincosf_glibc235.argtypes = [C.c_float, f32p, f32p, C.c_int]
     lib.orc_cexpf_imag_glibc235.argtypes = [C.c_float, f32p, f32p, C.c_int]
     lib.orc_detect_libm_variant.restype = C.c_int
@@ -114,6 +118,15 @@ def ccexpf_imag_array(theta, mode=0):
     t = np.ascontiguousarray(theta, dtype=np.float32)
     out = np.empty(t.size, dtype=complex32)
     lib.orc_ccexpf_imag_array(t.ctypes.data, t.size, out.ctypes.data, int(mode))
+    return out
+
+
+def ccexpf_array(z, mode=0):
+    """General ccexpf (complex.c:33-39) per element. mode 0: libm / reference complex.c; 1: restated glibc
+    cexpf with the FMA builds of expf/sincosf; 2: with the SSE2 builds."""
+    a = np.ascontiguousarray(z, dtype=complex32).reshape(-1)
+    out = np.empty(a.size, dtype=complex32)
+    lib.orc_ccexpf_array(a.ctypes.data, a.size, out.ctypes.data, int(mode))
     return out
 
 

@@ -135,6 +135,124 @@ void orc_cexpf_imag_glibc235(float theta, float *re, float *im, int fused)
     *im = s;
 }
 
+/* ------------------------------------------------------------------ expf ---- */
+static const uint64_t EXP2F_T[32] = {
+    0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b,
+    0x3fef54873168b9aa, 0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb,
+    0x3feedea64c123422, 0x3feece086061892d, 0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429,
+    0x3feea47eb03a5585, 0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74, 0x3feea11473eb0187, 0x3feea589994cce13,
+    0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d, 0x3feee89f995ad3ad,
+    0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f,
+    0x3fefa4afa2a490da, 0x3fefd0765b6e4540,
+};
+
+float orc_expf_glibc235(float x, int fused)
+{
+    const double SHIFT = 0x1.8p+52, InvLn2N = 0x1.71547652b82fep+5;
+    const double C0 = 0x1.c6af84b912394p-20, C1 = 0x1.ebfce50fac4f3p-13, C2 = 0x1.62e42ff0c52d6p-6;
+    const double xd = (double)x;
+    const uint32_t abstop = (asuint(x) >> 20) & 0x7ff;
+    if (abstop >= 0x42b) {                      /* |x| >= 88 or nan */
+        if (asuint(x) == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8) return x + x;
+        if (x > 0x1.62e42ep6f) { volatile float h = 0x1p97f; return h * h; }          /* overflow: +inf */
+        if (x < -0x1.9fe368p6f) { volatile float t = 0x1p-95f; return t * t; }        /* underflow: +0 */
+        if (x < -0x1.9d1d9ep6f) { volatile float t = 0x1.4p-75f; return t * t; }      /* may underflow: 2^-149 */
+    }
+    double kd, r;
+    if (fused) {
+        kd = __builtin_fma(InvLn2N, xd, SHIFT);
+    } else {
+        const double z = InvLn2N * xd;
+        kd = z + SHIFT;
+    }
+    uint64_t ki;
+    memcpy(&ki, &kd, 8);
+    kd -= SHIFT;
+    if (fused) {
+        r = __builtin_fma(InvLn2N, xd, -kd);
+    } else {
+        const double z = InvLn2N * xd;
+        r = z - kd;
+    }
+    uint64_t t = EXP2F_T[ki % 32];
+    t += ki << (52 - 5);
+    double sc;
+    memcpy(&sc, &t, 8);
+    const double z2 = mad(C0, r, C1, fused);
+    const double r2 = r * r;
+    double y = mad(C2, r, 1.0, fused);
+    y = mad(z2, r2, y, fused);
+    y = y * sc;
+    return (float)y;
+}
+
+/* ----------------------------------------------------------------- cexpf ---- */
+void orc_ccexpf_glibc235(float re, float im, float *out_re, float *out_im, int fused)
+{
+    /* complex.c:34: float complex input = a->real + a->imag * I;   (imag * (0 + 1i), then real + that) */
+    volatile float zero = 0.0f;
+    float xr = re + im * zero;
+    const float xi = im;
+    /* math/s_cexp_template.c for float */
+    const int r_fin = isfinite(xr), i_fin = isfinite(xi);
+    float rr, ri;
+    if (r_fin) {
+        if (i_fin) {
+            const int t = 88;                   /* (int)((FLT_MAX_EXP - 1) * M_LN2f) */
+            float sinix, cosix;
+            if (fabsf(xi) > FLT_MIN) orc_sincosf_glibc235(xi, &sinix, &cosix, fused);
+            else { sinix = xi; cosix = 1.0f; }
+            if (xr > t) {
+                const float exp_t = orc_expf_glibc235((float)t, fused);
+                xr -= t;
+                sinix *= exp_t;
+                cosix *= exp_t;
+                if (xr > t) {
+                    xr -= t;
+                    sinix *= exp_t;
+                    cosix *= exp_t;
+                }
+            }
+            if (xr > t) {
+                rr = FLT_MAX * cosix;
+                ri = FLT_MAX * sinix;
+            } else {
+                const float exp_val = orc_expf_glibc235(xr, fused);
+                rr = exp_val * cosix;
+                ri = exp_val * sinix;
+            }
+        } else {
+            rr = ri = NAN;
+        }
+    } else if (isinf(xr)) {
+        if (i_fin) {
+            const float value = signbit(xr) ? 0.0f : HUGE_VALF;
+            if (xi == 0.0f) {
+                rr = value;
+                ri = xi;
+            } else {
+                float sinix, cosix;
+                if (fabsf(xi) > FLT_MIN) orc_sincosf_glibc235(xi, &sinix, &cosix, fused);
+                else { sinix = xi; cosix = 1.0f; }
+                rr = copysignf(value, cosix);
+                ri = copysignf(value, sinix);
+            }
+        } else if (!signbit(xr)) {
+            rr = HUGE_VALF;
+            ri = xi - xi;
+        } else {
+            rr = 0.0f;
+            ri = copysignf(0.0f, xi);
+        }
+    } else {
+        rr = NAN;
+        ri = (xi == 0.0f) ? xi : NAN;
+    }
+    *out_re = rr;
+    *out_im = ri;
+}
+
 /* The only 17 magnitudes (x2 signs) out of all 2^32 floats on which the two
    contraction variants give different results (found by exhaustive search,
    all in the scaled-int reduction range); they discriminate the ifunc choice. */

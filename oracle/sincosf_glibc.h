@@ -35,6 +35,17 @@ void orc_sincosf_glibc235(float y, float *sinp, float *cosp, int fma_variant);
  * zero real part: |theta| > FLT_MIN -> sincosf, else (cos,sin) = (1, theta). */
 void orc_cexpf_imag_glibc235(float theta, float *re, float *im, int fma_variant);
 
+/* glibc 2.35 expf (sysdeps/ieee754/flt-32/e_expf.c, Szabolcs Nagy's optimized-routines expf: double
+ * evaluation, 32-entry 2^(i/32) table, cubic) — needed for ccexpf arguments with a real part
+ * (/root/reference/src/dsp.rs:57-83 test_cexpf).  fma_variant as above: __expf_fma fuses
+ * z*InvLn2N+SHIFT, InvLn2N*x-kd and every polynomial step; __expf_sse2 fuses nothing.
+ * Constants read from libm.so.6 .rodata (0xb2b80: table, 0xb2ca0..0xb2cc0: SHIFT, InvLn2N, C0..C2). */
+float orc_expf_glibc235(float x, int fma_variant);
+
+/* glibc 2.35 cexpf (math/s_cexp_template.c) on top of the two functions above, preceded by the
+ * argument construction of /root/reference/src/complex.c:34 (`real + imag * I`). */
+void orc_ccexpf_glibc235(float re, float im, float *out_re, float *out_im, int fma_variant);
+
 /* Which variant is bit-identical to this host's libm on a 1M-point probe:
  * 1 (fma), 0 (sse2) or -1 (neither; unexpected libm). */
 int orc_detect_libm_variant(void);

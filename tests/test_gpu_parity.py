@@ -76,11 +76,60 @@ def test_ccexpf_strided_sweep_of_all_floats(ctx, orc):
         assert_same_bytes(got, orc.ccexpf_imag_array(theta, mode=1), "f32", "sweep part %d" % part)
 
 
-def test_reference_known_answer_on_device(ctx):
-    """The one vector of the reference's test_cexpf (dsp.rs:62-65) that lies on the hot path: (0,0) -> (1,0)."""
+def test_reference_known_answers_on_device(ctx, orc):
+    """The reference's own test_cexpf (src/dsp.rs:57-83) against the device ccexpf, same vectors, same tolerance;
+    and bit-exact against the golden values produced through the reference's complex.c."""
     from doppler_amd import dsp
-    got = dsp.ccexpf(np.zeros(1, dtype=dsp.complex32), ctx=ctx)
+
+    def rel_close(a, b, delta):
+        return abs((float(a) - float(b)) / float(b)) < delta
+
+    z = load_golden("reference_tests.npz")
+    kin = np.zeros(4, dtype=dsp.complex32)
+    kin["re"], kin["im"] = z["kat_in"][:, 0], z["kat_in"][:, 1]
+    got = dsp.ccexpf(kin, ctx=ctx)
     assert got["re"][0] == 1.0 and got["im"][0] == 0.0
+    assert rel_close(got["re"][1], 1.468694, 1e-6) and rel_close(got["im"][1], 2.2873552, 1e-6)
+    assert rel_close(got["re"][2], 1593075600000000000000000000000.0, 1e-6)
+    assert rel_close(got["im"][2], 1946674600000000000000000000000.0, 1e-6)
+    assert got["re"][3] == np.inf and got["im"][3] == -np.inf
+    assert got["re"].tobytes() == z["kat_out"][:, 0].astype(np.float32).tobytes()
+    assert got["im"].tobytes() == z["kat_out"][:, 1].astype(np.float32).tobytes()
+
+
+def test_general_ccexpf_matches_libm(ctx, orc):
+    """ccexpf with a real part (outside the streaming path, but it is what complex.c:33-39 is): 2 M random pairs over
+    all exponents, a grid of overflow / underflow / inf / nan corners, both libm builds."""
+    from doppler_amd import dsp
+    rng = np.random.default_rng(3)
+
+    def rand_floats(n):
+        e = rng.integers(0, 255, size=n).astype(np.uint32)
+        m = rng.integers(0, 1 << 23, size=n).astype(np.uint32)
+        s = rng.integers(0, 2, size=n).astype(np.uint32)
+        return ((s << 31) | (e << 23) | m).view(np.float32)
+
+    n = 2000000
+    re, im = rand_floats(n), rand_floats(n)
+    re[: n // 2] = rng.uniform(-110, 270, size=n // 2).astype(np.float32)
+    im[: n // 4] = rng.uniform(-200, 200, size=n // 4).astype(np.float32)
+    spec = np.array([0.0, -0.0, 1.0, -1.0, 88.0, 88.5, 88.72284, 89.0, 176.0, 176.5, 177.0, 264.0, 264.5, 265.0, 300.0, -103.0,
+                     -103.5, -103.97, -104.0, -150.0, 1e-45, -1e-45, 1.17549435e-38, np.inf, -np.inf, np.nan, 3.4028235e38,
+                     -3.4028235e38, 70.0, 1e6], dtype=np.float32)
+    gr, gi = np.meshgrid(spec, spec)
+    z = np.empty(n + gr.size, dtype=dsp.complex32)
+    z["re"] = np.concatenate([re, gr.ravel()])
+    z["im"] = np.concatenate([im, gi.ravel()])
+    got = dsp.ccexpf(z, ctx=ctx)
+    assert_same_bytes(got, orc.ccexpf_array(z, mode=1), "f32", "device ccexpf vs restated glibc cexpf")
+    if orc.libm_variant() == 1:
+        assert_same_bytes(got, orc.ccexpf_array(z, mode=0), "f32", "device ccexpf vs libm through complex.c")
+    ctx.set_libm_contraction(False)
+    try:
+        got0 = dsp.ccexpf(z, ctx=ctx)
+    finally:
+        ctx.set_libm_contraction(True)
+    assert_same_bytes(got0, orc.ccexpf_array(z, mode=2), "f32", "device ccexpf vs restated glibc cexpf (SSE2 builds)")
 
 
 # ------------------------------------------------------------------ A1-A6 through the operator entry points

@@ -66,6 +66,29 @@ def test_restated_sincosf_matches_libm(orc):
     assert a.tobytes() != c.tobytes()     # these arguments are exactly where the two libm builds differ
 
 
+def test_restated_expf_and_cexpf_match_libm(orc):
+    """Restated glibc expf (strided sweep of all floats; the exhaustive run is in DESIGN.md) and cexpf
+    (random pairs + overflow/underflow/inf/nan corners) against this host's libm."""
+    exe = os.path.join(ROOT, "oracle", "check_sincosf")
+    r = subprocess.run([exe, "--stride", "1021", "--expf", "--threads", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert '"expf_checked": 1' in r.stdout
+    variant = orc.libm_variant()
+    rng = np.random.default_rng(8)
+    n = 300000
+    z = np.empty(n + 36, dtype=orc.complex32)
+    z["re"][:n] = rng.uniform(-110, 270, size=n).astype(np.float32)
+    z["im"][:n] = (rng.standard_normal(n) * 10.0 ** rng.integers(-3, 6, size=n)).astype(np.float32)
+    spec = np.array([0.0, 88.5, 177.0, 265.0, -104.0, np.inf], dtype=np.float32)
+    gr, gi = np.meshgrid(spec, np.array([0.0, -0.0, 1.0, 1e6, np.inf, np.nan], dtype=np.float32))
+    z["re"][n:], z["im"][n:] = gr.ravel(), gi.ravel()
+    a = orc.ccexpf_array(z, mode=0)
+    b = orc.ccexpf_array(z, mode=1 if variant == 1 else 2)
+    same = ((a["re"].view(np.uint32) == b["re"].view(np.uint32)) | (np.isnan(a["re"]) & np.isnan(b["re"]))) & \
+           ((a["im"].view(np.uint32) == b["im"].view(np.uint32)) | (np.isnan(a["im"]) & np.isnan(b["im"])))
+    assert same.all(), z[~same][:5]
+
+
 def test_oracle_matches_golden_shift_cases(orc):
     n = 0
     for c in shift_block_cases():
