@@ -62,6 +62,14 @@ _SIGNATURES = {
     "dpx_plan_n_samples": (_i, [_vp, _P(_u64)]),
     "dpx_plan_final_samplenum": (_i, [_vp, _P(_u32)]),
     "dpx_plan_destroy": (None, [_vp]),
+    "dpx_stream_create": (_i, [_vp, _i, _i, _u32, _u32, _sz, _i, _P(_vp)]),
+    "dpx_stream_acquire": (_i, [_vp, _P(_vp), _P(_sz)]),
+    "dpx_stream_submit": (_i, [_vp, _sz, _P(Segment), _sz]),
+    "dpx_stream_pending": (_i, [_vp, _P(_i)]),
+    "dpx_stream_next": (_i, [_vp, _P(_vp), _P(_sz)]),
+    "dpx_stream_release": (_i, [_vp]),
+    "dpx_stream_samplenum": (_i, [_vp, _P(_u32)]),
+    "dpx_stream_destroy": (None, [_vp]),
     "dpx_run_device": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "dpx_debug_copy": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "dpx_set_tuning": (_i, [_vp, _i, _i, _i]),

@@ -8,10 +8,10 @@
 //   * the sample counter `samplenr` (main.rs:60) is carried through the whole run.
 // What changes is the granularity of the work: blocks are gathered into slabs (as many complete
 // blocks as are available without waiting, up to DOPPLER_SLAB_BYTES), each slab is one plan + one
-// fused launch, and three slabs rotate so that reading, PCIe copies, the kernel and writing overlap.
+// fused launch, and three slabs rotate (the dpx_stream_* ring of the C ABI) so that reading, PCIe
+// copies, the kernel and writing overlap.
 // A live 1 Msps pipe therefore still moves in ~8-64 KiB steps, a file at PCIe speed.
 #include <errno.h>
-#include <hip/hip_runtime_api.h>
 #include <poll.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -52,15 +52,6 @@ void info(const char *fmt, ...)
     fputc('\n', stderr);
 }
 
-#define HIPCHK(call)                                                                     \
-    do {                                                                                 \
-        hipError_t e_ = (call);                                                          \
-        if (e_ != hipSuccess) {                                                          \
-            fprintf(stderr, "doppler: %s failed: %s\n", #call, hipGetErrorString(e_));    \
-            exit(1);                                                                     \
-        }                                                                                \
-    } while (0)
-
 #define DPXCHK(call)                                                                     \
     do {                                                                                 \
         int rc_ = (call);                                                                \
@@ -69,16 +60,6 @@ void info(const char *fmt, ...)
             exit(1);                                                                     \
         }                                                                                \
     } while (0)
-
-struct Slab {
-    char *h_in = nullptr, *h_out = nullptr;
-    void *d_in = nullptr, *d_out = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;
-    dpx_plan *plan = nullptr;
-    size_t out_bytes = 0;
-    bool in_flight = false;
-};
 
 bool write_all(int fd, const char *p, size_t n)
 {
@@ -130,7 +111,7 @@ int main(int argc, char **argv)
 
     const int in_fmt = args.inputtype == dpx::DataType::I16 ? DPX_FMT_I16 : DPX_FMT_F32;
     const int out_fmt = args.outputtype == dpx::DataType::I16 ? DPX_FMT_I16 : DPX_FMT_F32;
-    const size_t ibs = in_fmt == DPX_FMT_I16 ? 4 : 8, obs = out_fmt == DPX_FMT_I16 ? 4 : 8;
+    const size_t ibs = in_fmt == DPX_FMT_I16 ? 4 : 8;
 
     info("doppler %s (MI355X hot path)\n\n", "1.1.10");
     std::function<double(int64_t)> range_rate;      // replay: seconds since --time
@@ -202,33 +183,28 @@ int main(int argc, char **argv)
     if (const char *e = getenv("DOPPLER_SLAB_BYTES")) slab_bytes = strtoull(e, nullptr, 0);
     slab_bytes = (slab_bytes / DPX_BUFFER_SIZE) * DPX_BUFFER_SIZE;
     if (slab_bytes < DPX_BUFFER_SIZE) slab_bytes = DPX_BUFFER_SIZE;
-    const size_t slab_out = slab_bytes / ibs * obs;
 
-    constexpr int kSlabs = 3;
-    Slab slabs[kSlabs];
-    for (Slab &s : slabs) {
-        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s.h_in), slab_bytes, hipHostMallocDefault));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s.h_out), slab_out, hipHostMallocDefault));
-        HIPCHK(hipMalloc(&s.d_in, slab_bytes));
-        HIPCHK(hipMalloc(&s.d_out, slab_out));
-        HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-    }
+    // three pinned slabs in rotation (include/doppler_hip.h, "streaming from host memory")
+    dpx_stream *stream = nullptr;
+    DPXCHK(dpx_stream_create(ctx, in_fmt, out_fmt, args.samplerate, /*samplenr, main.rs:60*/ 0, slab_bytes, 3, &stream));
 
-    auto retire = [&](Slab &s) {        // in stream order: wait, write, free the plan
-        if (!s.in_flight) return;
-        HIPCHK(hipEventSynchronize(s.done));
-        if (!write_all(STDOUT_FILENO, s.h_out, s.out_bytes)) {
+    auto drain_one = [&]() {            // oldest slab: wait, write to stdout, free
+        const void *out = nullptr;
+        size_t nbytes = 0;
+        DPXCHK(dpx_stream_next(stream, &out, &nbytes));
+        if (!write_all(STDOUT_FILENO, static_cast<const char *>(out), nbytes)) {
             info("doppler stdout.write error: %s", strerror(errno));       // main.rs:86
             exit(1);
         }
-        dpx_plan_destroy(s.plan);
-        s.plan = nullptr;
-        s.in_flight = false;
+        DPXCHK(dpx_stream_release(stream));
+    };
+    auto pending = [&]() {
+        int n = 0;
+        DPXCHK(dpx_stream_pending(stream, &n));
+        return n;
     };
 
     // the reference's loop state
-    uint32_t samplenr = 0;                                                   // main.rs:60
     const bool replay = args.mode == dpx::Mode::Track && args.has_time;
     std::unique_ptr<dpx::ReplaySchedule> sched;
     if (args.mode == dpx::Mode::Track) {
@@ -242,25 +218,27 @@ int main(int argc, char **argv)
     double last_wall_log = 0;
 
     bool eof = false, ragged = false;
-    int cur = 0;
     uint64_t total_samples = 0;
     struct timeval tv_start;
     gettimeofday(&tv_start, nullptr);
     std::vector<dpx_segment> segs;
     while (!eof) {
-        Slab &s = slabs[cur];
-        retire(s);                         // this slab's previous contents must be out before it is overwritten
-        size_t n = gather(STDIN_FILENO, s.h_in, slab_bytes, &eof);
+        void *buf = nullptr;
+        size_t cap = 0;
+        if (pending() == 3) drain_one();   // every slab in flight: the oldest must be written out first
+        DPXCHK(dpx_stream_acquire(stream, &buf, &cap));
+        const size_t n = gather(STDIN_FILENO, static_cast<char *>(buf), cap, &eof);
         // main.rs:63-68: complete blocks always; the trailing short block only if it is whole samples
+        // (gather() stops only on block boundaries unless the input ended, so tail != 0 implies eof)
         const size_t full = n / DPX_BUFFER_SIZE * DPX_BUFFER_SIZE;
         size_t tail = n - full;
-        // (gather() stops only on block boundaries unless the input ended, so tail != 0 implies eof)
         if (tail % ibs != 0) {
             ragged = true;                 // the reference panics on this block: no output for it
             tail = 0;
         }
         const size_t use = full + tail;
         const size_t n_samples = use / ibs;
+        total_samples += n_samples;
 
         // shift schedule for the blocks of this slab
         segs.clear();
@@ -308,27 +286,12 @@ int main(int argc, char **argv)
                 else segs.push_back({(uint64_t)cnt, hz});
             }
         }
-
-        total_samples += n_samples;
-        if (n_samples) {
-            DPXCHK(dpx_plan_segments(ctx, segs.data(), segs.size(), args.samplerate, samplenr, &s.plan));
-            DPXCHK(dpx_plan_final_samplenum(s.plan, &samplenr));
-            s.out_bytes = n_samples * obs;
-            HIPCHK(hipMemcpyAsync(s.d_in, s.h_in, use, hipMemcpyHostToDevice, s.stream));
-            DPXCHK(dpx_run_device(s.plan, s.d_in, in_fmt, s.d_out, out_fmt, s.stream));
-            HIPCHK(hipMemcpyAsync(s.h_out, s.d_out, s.out_bytes, hipMemcpyDeviceToHost, s.stream));
-            HIPCHK(hipEventRecord(s.done, s.stream));
-            s.in_flight = true;
-        }
-        cur = (cur + 1) % kSlabs;
-        // keep at most kSlabs-1 slabs in flight and the output in order: the oldest is retired
-        // at the top of the loop when its buffer comes round again; on a live pipe do it now
-        // so that the latency stays one slab
-        if (n < slab_bytes) {
-            for (int k = 0; k < kSlabs; ++k) retire(slabs[(cur + k) % kSlabs]);
-        }
+        DPXCHK(dpx_stream_submit(stream, use, segs.data(), segs.size()));
+        // a slab that did not fill means the producer is slower than we are (a live pipe): hand the
+        // output over now instead of when the ring comes round, so that the latency stays one slab
+        if (n < cap) while (pending()) drain_one();
     }
-    for (int k = 0; k < kSlabs; ++k) retire(slabs[(cur + k) % kSlabs]);
+    while (pending()) drain_one();
 
     if (getenv("DOPPLER_STATS")) {      // steady-state rate: first read to last write, start-up excluded
         struct timeval tv_end;
@@ -337,14 +300,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "doppler stats: %llu samples in %.6f s = %.1f Msamples/s (stdin -> stdout, start-up excluded)\n",
                 (unsigned long long)total_samples, dt, total_samples / dt / 1e6);
     }
-    for (Slab &s : slabs) {
-        (void)hipHostFree(s.h_in);
-        (void)hipHostFree(s.h_out);
-        (void)hipFree(s.d_in);
-        (void)hipFree(s.d_out);
-        (void)hipStreamDestroy(s.stream);
-        (void)hipEventDestroy(s.done);
-    }
+    dpx_stream_destroy(stream);
     dpx_ctx_destroy(ctx);
     if (ragged) {
         fprintf(stderr, "thread 'main' panicked at 'assertion failed: inbuf.len() %% %zu == 0'\n", ibs);

@@ -588,6 +588,176 @@ int dpx_run_device(dpx_plan *plan, const void *d_in, int in_fmt, void *d_out, in
     return run_plan(plan->host, plan->dev, d_in, in_fmt, d_out, out_fmt, plan->fma, plan->geom, hip_stream);
 }
 
+/* ------------------------------------------------------------------ streaming */
+
+struct dpx_stream_slab {
+    char *h_in = nullptr, *h_out = nullptr;
+    void *d_in = nullptr, *d_out = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    dpx::PlanResult plan;
+    DevPlan dev;
+    size_t out_bytes = 0;
+    int state = 0;      // 0 free, 1 acquired (being filled), 2 in flight, 3 handed out by next()
+};
+
+struct dpx_stream {
+    dpx_ctx *ctx = nullptr;
+    int in_fmt = 0, out_fmt = 0;
+    uint32_t samplerate = 0, samplenum = 0;
+    size_t slab_bytes = 0, slab_out = 0;
+    std::vector<dpx_stream_slab> slabs;
+    size_t head = 0;    // next slab to acquire
+    size_t tail = 0;    // oldest submitted slab
+    int in_flight = 0;
+};
+
+int dpx_stream_create(dpx_ctx *ctx, int in_fmt, int out_fmt, uint32_t samplerate, uint32_t samplenum0,
+                      size_t slab_bytes, int n_slabs, dpx_stream **out)
+{
+    if (!ctx || !out || !fmt_ok(in_fmt) || !fmt_ok(out_fmt) || n_slabs < 1 || n_slabs > 64)
+        return fail(DPX_ERR_ARG, "bad argument");
+    *out = nullptr;
+    const size_t ibs = bytes_per_sample(in_fmt), obs = bytes_per_sample(out_fmt);
+    slab_bytes = slab_bytes / 16 * 16;
+    if (slab_bytes < 16) return fail(DPX_ERR_ARG, "slab_bytes must be at least 16");
+    DPX_HIP(hipSetDevice(ctx->device));
+    dpx_stream *s = new (std::nothrow) dpx_stream;
+    if (!s) return fail(DPX_ERR_ARG, "out of host memory");
+    s->ctx = ctx;
+    s->in_fmt = in_fmt;
+    s->out_fmt = out_fmt;
+    s->samplerate = samplerate;
+    s->samplenum = samplenum0;
+    s->slab_bytes = slab_bytes;
+    s->slab_out = slab_bytes / ibs * obs;
+    s->slabs.resize((size_t)n_slabs);
+    for (dpx_stream_slab &b : s->slabs) {
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&b.h_in), slab_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_out), s->slab_out + 16, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(&b.d_in, slab_bytes);
+        if (e == hipSuccess) e = hipMalloc(&b.d_out, s->slab_out + 16);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            dpx_stream_destroy(s);
+            return fail(DPX_ERR_HIP, "stream slab allocation failed: %s", hipGetErrorString(e));
+        }
+    }
+    *out = s;
+    return DPX_OK;
+}
+
+void dpx_stream_destroy(dpx_stream *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    for (dpx_stream_slab &b : s->slabs) {
+        if (b.stream) (void)hipStreamSynchronize(b.stream);
+        if (b.h_in) (void)hipHostFree(b.h_in);
+        if (b.h_out) (void)hipHostFree(b.h_out);
+        if (b.d_in) (void)hipFree(b.d_in);
+        if (b.d_out) (void)hipFree(b.d_out);
+        release(b.dev);
+        if (b.done) (void)hipEventDestroy(b.done);
+        if (b.stream) (void)hipStreamDestroy(b.stream);
+    }
+    delete s;
+}
+
+int dpx_stream_acquire(dpx_stream *s, void **pinned_in, size_t *capacity_bytes)
+{
+    if (!s || !pinned_in) return fail(DPX_ERR_ARG, "bad argument");
+    dpx_stream_slab &b = s->slabs[s->head];
+    if (b.state == 1) {             // acquire twice without submit: same buffer again
+        *pinned_in = b.h_in;
+        if (capacity_bytes) *capacity_bytes = s->slab_bytes;
+        return DPX_OK;
+    }
+    if (b.state != 0) return fail(DPX_ERR_PLAN, "all %zu slabs are in flight: call dpx_stream_next/release first", s->slabs.size());
+    b.state = 1;
+    *pinned_in = b.h_in;
+    if (capacity_bytes) *capacity_bytes = s->slab_bytes;
+    return DPX_OK;
+}
+
+int dpx_stream_submit(dpx_stream *s, size_t in_bytes, const dpx_segment *segs, size_t n_segs)
+{
+    if (!s || (n_segs && !segs)) return fail(DPX_ERR_ARG, "bad argument");
+    dpx_stream_slab &b = s->slabs[s->head];
+    if (b.state != 1) return fail(DPX_ERR_PLAN, "dpx_stream_submit without dpx_stream_acquire");
+    const size_t ibs = bytes_per_sample(s->in_fmt), obs = bytes_per_sample(s->out_fmt);
+    if (in_bytes > s->slab_bytes) return fail(DPX_ERR_CAPACITY, "%zu bytes exceed the slab (%zu)", in_bytes, s->slab_bytes);
+    if (in_bytes % ibs != 0)
+        return fail(DPX_ERR_BLOCK_LEN, "%zu bytes is not a whole number of samples", in_bytes);
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_segs; ++i) total += segs[i].n_samples;
+    if (total != in_bytes / ibs) return fail(DPX_ERR_PLAN, "segments hold %llu samples, the slab %zu",
+                                             (unsigned long long)total, in_bytes / ibs);
+    dpx_ctx *ctx = s->ctx;
+    DPX_HIP(hipSetDevice(ctx->device));
+    b.plan = dpx::PlanResult();
+    uint32_t sn = s->samplenum;
+    for (size_t i = 0; i < n_segs; ++i)
+        dpx::plan_append(b.plan, dpx::ratio_of(segs[i].shift_hz, s->samplerate), segs[i].n_samples, sn, ctx->variant);
+    const dpx::LaunchGeom g = geometry(ctx);
+    dpx::finalize(b.plan, g.tile(), ctx->use_rows);
+    if (b.plan.error) return fail(DPX_ERR_PLAN, "%s", b.plan.error);
+    b.out_bytes = (size_t)total * obs;
+    if (total) {
+        int rc = materialize(ctx, b.plan, b.dev, ctx->fma, b.stream);
+        if (rc != DPX_OK) return rc;
+        DPX_HIP(hipMemcpyAsync(b.d_in, b.h_in, in_bytes, hipMemcpyHostToDevice, b.stream));
+        rc = run_plan(b.plan, b.dev, b.d_in, s->in_fmt, b.d_out, s->out_fmt, ctx->fma, g, b.stream);
+        if (rc != DPX_OK) return rc;
+        DPX_HIP(hipMemcpyAsync(b.h_out, b.d_out, b.out_bytes, hipMemcpyDeviceToHost, b.stream));
+    }
+    DPX_HIP(hipEventRecord(b.done, b.stream));
+    s->samplenum = sn;
+    b.state = 2;
+    s->head = (s->head + 1) % s->slabs.size();
+    s->in_flight++;
+    return DPX_OK;
+}
+
+int dpx_stream_pending(const dpx_stream *s, int *n)
+{
+    if (!s || !n) return fail(DPX_ERR_ARG, "bad argument");
+    *n = s->in_flight;
+    return DPX_OK;
+}
+
+int dpx_stream_next(dpx_stream *s, const void **pinned_out, size_t *out_bytes)
+{
+    if (!s || !pinned_out || !out_bytes) return fail(DPX_ERR_ARG, "bad argument");
+    dpx_stream_slab &b = s->slabs[s->tail];
+    if (b.state == 3) return fail(DPX_ERR_PLAN, "dpx_stream_next twice without dpx_stream_release");
+    if (b.state != 2) return fail(DPX_ERR_PLAN, "nothing in flight");
+    DPX_HIP(hipEventSynchronize(b.done));
+    b.state = 3;
+    *pinned_out = b.h_out;
+    *out_bytes = b.out_bytes;
+    return DPX_OK;
+}
+
+int dpx_stream_release(dpx_stream *s)
+{
+    if (!s) return fail(DPX_ERR_ARG, "bad argument");
+    dpx_stream_slab &b = s->slabs[s->tail];
+    if (b.state != 3) return fail(DPX_ERR_PLAN, "dpx_stream_release without dpx_stream_next");
+    b.state = 0;
+    s->tail = (s->tail + 1) % s->slabs.size();
+    s->in_flight--;
+    return DPX_OK;
+}
+
+int dpx_stream_samplenum(const dpx_stream *s, uint32_t *samplenum)
+{
+    if (!s || !samplenum) return fail(DPX_ERR_ARG, "bad argument");
+    *samplenum = s->samplenum;
+    return DPX_OK;
+}
+
 int dpx_debug_copy(dpx_ctx *ctx, const void *d_in, void *d_out, size_t n_bytes, void *hip_stream)
 {
     if (!ctx || !d_in || !d_out || (n_bytes & 15u)) return fail(DPX_ERR_ARG, "bad argument");

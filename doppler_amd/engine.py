@@ -153,6 +153,62 @@ class Plan:
             pass
 
 
+class Stream:
+    """Ring of pinned host slabs (dpx_stream_*): fill a slab, submit it with its constant-shift segments, collect
+    the outputs in order.  The sample counter is carried from slab to slab like `samplenr` (main.rs:60)."""
+
+    def __init__(self, ctx, in_fmt, out_fmt, samplerate, samplenum=0, slab_bytes=8 << 20, n_slabs=3):
+        self._lib = _lib_handle()
+        self.ctx = ctx
+        self.in_fmt, self.out_fmt = fmt_code(in_fmt), fmt_code(out_fmt)
+        self._h = C.c_void_p()
+        check(self._lib.dpx_stream_create(ctx.handle, self.in_fmt, self.out_fmt, int(samplerate), int(samplenum),
+                                          int(slab_bytes), int(n_slabs), C.byref(self._h)))
+
+    def acquire(self):
+        """numpy uint8 view of the next free pinned input slab (raises DspError ERR_PLAN when all are in flight)."""
+        p, cap = C.c_void_p(), C.c_size_t()
+        check(self._lib.dpx_stream_acquire(self._h, C.byref(p), C.byref(cap)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(cap.value,))
+
+    def submit(self, in_bytes, segments):
+        arr = (_lib.Segment * max(1, len(segments)))()
+        for i, (n, hz) in enumerate(segments):
+            arr[i].n_samples = int(n)
+            arr[i].shift_hz = float(hz)
+        check(self._lib.dpx_stream_submit(self._h, int(in_bytes), arr, len(segments)))
+
+    def pending(self):
+        n = C.c_int()
+        check(self._lib.dpx_stream_pending(self._h, C.byref(n)))
+        return n.value
+
+    def next(self):
+        """Waits for the oldest submitted slab; returns a COPY of its output bytes and frees the slab."""
+        p, nb = C.c_void_p(), C.c_size_t()
+        check(self._lib.dpx_stream_next(self._h, C.byref(p), C.byref(nb)))
+        out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(nb.value, 1),))[: nb.value].copy()
+        check(self._lib.dpx_stream_release(self._h))
+        return out
+
+    @property
+    def samplenum(self):
+        n = C.c_uint32()
+        check(self._lib.dpx_stream_samplenum(self._h, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.dpx_stream_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 _default = None
 
 

@@ -180,6 +180,31 @@ void dpx_plan_destroy(dpx_plan *plan);
 int dpx_run_device(dpx_plan *plan, const void *d_in, int in_fmt, void *d_out, int out_fmt,
                    void *hip_stream);
 
+/* ------------------------------------------------ streaming from host memory
+ * What the reference's driver loop (src/main.rs:57-99: read a block from stdin, shift, write to
+ * stdout) becomes when the blocks are gathered into slabs: a ring of pinned host slabs, each slab
+ * one plan + one fused launch on its own HIP stream, so that filling, PCIe copies, the kernel and
+ * draining overlap.  Zero-copy on the host side: the caller reads into / writes out of the pinned
+ * buffers.  The sample counter (`samplenr`, main.rs:60) is carried from slab to slab.
+ *
+ *   dpx_stream_acquire  -> pinned input buffer of the next free slab (slab_bytes capacity); when
+ *                          every slab is in flight it returns DPX_ERR_PLAN: drain one first
+ *   dpx_stream_submit   -> that slab now holds in_bytes of IQ with the given constant-shift
+ *                          segments (their sample counts must add up to in_bytes); asynchronous
+ *   dpx_stream_next     -> oldest submitted slab: waits for it, returns its pinned output
+ *   dpx_stream_release  -> that output has been consumed; the slab is free again
+ * Outputs come back in submission order. */
+typedef struct dpx_stream dpx_stream;
+int dpx_stream_create(dpx_ctx *ctx, int in_fmt, int out_fmt, uint32_t samplerate, uint32_t samplenum0,
+                      size_t slab_bytes, int n_slabs, dpx_stream **stream);
+int dpx_stream_acquire(dpx_stream *s, void **pinned_in, size_t *capacity_bytes);
+int dpx_stream_submit(dpx_stream *s, size_t in_bytes, const dpx_segment *segs, size_t n_segs);
+int dpx_stream_pending(const dpx_stream *s, int *n_in_flight);
+int dpx_stream_next(dpx_stream *s, const void **pinned_out, size_t *out_bytes);
+int dpx_stream_release(dpx_stream *s);
+int dpx_stream_samplenum(const dpx_stream *s, uint32_t *samplenum);   /* counter after everything submitted */
+void dpx_stream_destroy(dpx_stream *s);
+
 /* Same access pattern, no arithmetic: 16-byte non-temporal copy of n_bytes.
  * Calibration only (profiles/: what the memory system gives a pure stream). */
 int dpx_debug_copy(dpx_ctx *ctx, const void *d_in, void *d_out, size_t n_bytes, void *hip_stream);

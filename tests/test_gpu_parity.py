@@ -424,3 +424,56 @@ def test_c_abi_error_paths(ctx):
     with pytest.raises(doppler_amd.DspError) as e:
         doppler_amd.Context(99)
     assert e.value.code == _lib.ERR_NO_DEVICE
+
+
+def test_stream_api_ring_of_slabs(ctx, orc):
+    """dpx_stream_*: slabs of unequal size, shift changes inside and between slabs, the ring filled to capacity,
+    outputs collected in order — equal to the oracle run over the concatenated stream with the counter carried."""
+    import doppler_amd
+    from doppler_amd import _lib
+    rate = 256000
+    rng = np.random.default_rng(31)
+    st = doppler_amd.Stream(ctx, "f32", "i16", rate, samplenum=0, slab_bytes=1 << 20, n_slabs=3)
+    plan = []       # (n_samples, [(cnt, hz), ...]) per slab
+    for k in range(8):
+        n = int(rng.integers(1, (1 << 20) // 8 + 1)) if k != 3 else (1 << 20) // 8
+        if k == 5:
+            n = 0
+        cuts = sorted(set(int(c) for c in rng.integers(0, n + 1, size=2))) if n else []
+        bounds = [0] + [c for c in cuts if 0 < c < n] + [n]
+        segs = [(b - a, float(np.float32(rng.uniform(-9000, 9000)))) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+        plan.append((n, segs))
+    total = sum(n for n, _ in plan)
+    x = make_iq("f32", total, 88)
+    outs, pos, submitted = [], 0, 0
+    for n, segs in plan:
+        if st.pending() == 3:
+            with pytest.raises(doppler_amd.DspError) as e:      # ring full: acquire must refuse, not overwrite
+                st.acquire()
+            assert e.value.code == _lib.ERR_PLAN
+            outs.append(st.next())
+        buf = st.acquire()
+        buf[: n * 8] = x[pos * 8:(pos + n) * 8]
+        st.submit(n * 8, segs)
+        pos += n
+        submitted += 1
+    while st.pending():
+        outs.append(st.next())
+    got = np.concatenate(outs)
+    cx = orc.convert_iqf32_to_complex(x)
+    ref, sn, pos = [], 0, 0
+    for n, segs in plan:
+        for cnt, hz in segs:
+            o, sn = orc.shift_frequency(cx[pos:pos + cnt], sn, hz, rate)
+            ref.append(o)
+            pos += cnt
+    assert st.samplenum == sn
+    assert_same_bytes(got, orc.pack_i16(np.concatenate(ref)), "i16", "stream ring")
+    with pytest.raises(doppler_amd.DspError):
+        st.submit(8, [(1, 1.0)])                                # submit without acquire
+    buf = st.acquire()
+    with pytest.raises(doppler_amd.DspError):
+        st.submit(12, [(1, 1.0)])                               # 12 bytes is not a whole f32 sample (dsp.rs:103)
+    with pytest.raises(doppler_amd.DspError):
+        st.submit(16, [(1, 1.0)])                               # segments do not add up
+    st.close()
