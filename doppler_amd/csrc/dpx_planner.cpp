@@ -127,7 +127,7 @@ constexpr uint64_t kRowsMinSamples = 1u << 16;   // below this a stretch stays o
 constexpr uint64_t kAbsorbMax = 4096;            // neighbouring crumbs a rows launch may evaluate itself
 constexpr size_t kRowsMaxLaunches = 8;           // more tabulated stretches than this: one tile launch instead
 
-// Row length for period P: a multiple of lcm(P, 4) not above kRowsMaxL, scored from measurements on
+// Row length for period P: lcm(P, 4) (if not above kRowsMaxL) or a multiple of it up to kRowsMultMaxL, scored from measurements on
 // MI355X (profiles/r01_membench.md section 4), i16 stream, GB/s relative to the best case:
 //   rows that do not start on a 128-byte line (L % 32 != 0): -20 % (a wavefront's 1 KiB piece then
 //     shares lines with wavefronts running on other XCDs);
@@ -149,7 +149,7 @@ uint32_t pick_row_length(uint32_t P)
     }
     uint32_t best = 0;
     double best_score = -1e9;
-    for (uint64_t L = base; L <= max_l; L += base) {
+    for (uint64_t L = base; L <= max_l && (L == base || L <= kRowsMultMaxL); L += base) {
         double score = (double)L / (256.0 * (double)((L + 255) / 256));
         if (L % 32 != 0) score -= 0.20;
         if (L % 1024 != 0) score -= 0.03;

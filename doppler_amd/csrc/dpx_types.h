@@ -43,7 +43,8 @@ struct StretchView {
 
 constexpr int kSamplesPerLane = 4;          // tile kernel: one 16-byte i16 vector = 4 IQ samples
 constexpr uint32_t kLutMaxEntries = 4194304; // longest tile-kernel table (32 MiB: beyond L2, inside the 256 MiB Infinity Cache)
-constexpr uint32_t kRowsMaxL = 131072;      // longest rows-kernel row / table (1 MiB)
+constexpr uint32_t kRowsMaxL = 4194304;     // longest rows-kernel row / table (32 MiB, Infinity-Cache resident)
+constexpr uint32_t kRowsMultMaxL = 131072;  // multiples of lcm(P, 4) are only considered up to this row length
 constexpr int kHintShift = 16;              // one stretch hint per 65536 samples
 constexpr int kRowsLanes = 64;              // rows kernel: one wavefront per workgroup
 
