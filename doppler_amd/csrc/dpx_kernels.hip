@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
                                                           const float2 *__restrict__ tab,   // table, origin = sample A
                                                           uint64_t A, uint32_t L, uint32_t cols,
                                                           uint64_t div_m, uint32_t div_s,
-                                                          uint32_t n_main,
+                                                          uint32_t n_main, uint32_t P,
                                                           // ---- ragged path only (not preloaded)
                                                           const DevSeg *__restrict__ segs,
                                                           RowsArgs ra)
@@ -209,8 +209,11 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
         for (int r = 0; r < R; ++r)
             q[r] = __builtin_nontemporal_load(reinterpret_cast<const qvec *>(in + (g0 + (uint64_t)r * L) * IB));
 
-        // S correctors, shared by the R rows: table origin is sample A, so the index is cs0
-        const u32x4 *tp = reinterpret_cast<const u32x4 *>(tab + cs0);
+        // S correctors, shared by the R rows.  The table holds ONE period (+3 entries so that a group of 4 never
+        // wraps), origin = sample A; the row length is a multiple of the period, so the index is the column
+        // modulo the period — the column itself when a row is exactly one period (the headline case).
+        const uint32_t e0 = (L == P) ? cs0 : cs0 % P;
+        const u32x4 *tp = reinterpret_cast<const u32x4 *>(tab + e0);
         u32x4 t[S / 2];
 #pragma unroll
         for (int i = 0; i < S / 2; ++i) t[i] = tp[i];
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
     const DevSeg sg = segs[si];
     const bool whole = in_mask && (t0 >= sg.first) && (t0 + TILE <= sg.first + sg.count);
 
-    if (whole && sg.lut_len != 0 && !(sg.flags & kSegRows)) {
+    if (whole && sg.lut_len != 0 && (sg.flags & kSegTileTable)) {
         // ---- tabulated correctors: phase of t0 within the period, then straight indexing
         const uint32_t P = sg.period;
         // (c0 + t0) mod P with t0 = tile * TILE; 32-bit while (tile mod P) * tmod < 2^18 * 2^11
@@ -495,8 +498,8 @@ static int rows_t(const void *d_in, void *d_out, const DevSeg *d_segs, const voi
     const float2 *tab = lut + r.tab_off;
 #define DPX_ROWS_CASE(RR)                                                                                                                   \
     if (r.R == RR) {                                                                                                                        \
-        if (fma) rows_kernel<IN_FMT, OUT_FMT, true, RR><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_main, d_segs, r);  \
-        else     rows_kernel<IN_FMT, OUT_FMT, false, RR><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_main, d_segs, r); \
+        if (fma) rows_kernel<IN_FMT, OUT_FMT, true, RR><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_main, r.P, d_segs, r);  \
+        else     rows_kernel<IN_FMT, OUT_FMT, false, RR><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_main, r.P, d_segs, r); \
         return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                                                      \
     }
     DPX_ROWS_CASE(2) DPX_ROWS_CASE(4) DPX_ROWS_CASE(8)

@@ -127,36 +127,52 @@ constexpr uint64_t kRowsMinSamples = 1u << 16;   // below this a stretch stays o
 constexpr uint64_t kAbsorbMax = 4096;            // neighbouring crumbs a rows launch may evaluate itself
 constexpr size_t kRowsMaxLaunches = 8;           // more tabulated stretches than this: one tile launch instead
 
-// Row length for period P: lcm(P, 4) (if not above kRowsMaxL) or a multiple of it up to kRowsMultMaxL, scored from measurements on
-// MI355X (profiles/r01_membench.md section 4), i16 stream, GB/s relative to the best case:
-//   rows that do not start on a 128-byte line (L % 32 != 0): -20 % (a wavefront's 1 KiB piece then
-//     shares lines with wavefronts running on other XCDs);
-//   idle lanes in the last 256-sample column slice: proportional;
-//   rows that are not a whole number of 4 KiB pages (L % 1024 != 0): about -3 %;
-//   table size: about -2 % at 256 KiB, -3 % at 1 MiB (no longer L1-resident).
-// Returns 0 if no multiple fits.
-uint32_t pick_row_length(uint32_t P)
+uint64_t lcm_u64(uint64_t a, uint64_t b)
 {
-    uint64_t g = P, h = 4;
+    uint64_t g = a, h = b;
     while (h) { const uint64_t t = g % h; g = h; h = t; }
-    const uint64_t base = (uint64_t)P / g * 4;
-    uint64_t max_l = kRowsMaxL;
-    if (const char *e = getenv("DPX_ROWS_MAXL")) max_l = strtoull(e, nullptr, 0);   // measurement override
-    if (base > max_l) return 0;
+    return a / g * b;
+}
+
+// Row length for a stretch of period P with `body` samples available from the matrix origin and R rows per
+// wavefront.  L must be a multiple of P (a column then always sees the same corrector) and of 4 (16-byte rows);
+// the table is one period whatever L is, so L is chosen for the memory system alone, scored from measurements
+// on MI355X (profiles/r01_membench.md section 4, i16 stream, relative to the best case):
+//   rows that do not start on a 128-byte line (L % 32 != 0): -20 % (a wavefront's 1 KiB piece then shares
+//     lines with wavefronts running on other XCDs);
+//   rows that are not a whole number of 4 KiB pages (L % 1024 != 0): about -3 %;
+//   idle lanes in the last 256-sample column slice: proportional.
+// At least 16 row groups must fit.  Returns 0 if no such L exists.
+uint32_t pick_row_length(uint32_t P, uint64_t body, uint32_t R)
+{
+    uint64_t cap = std::min<uint64_t>(kRowsMaxL, body / (16ull * R));
+    if (const char *e = getenv("DPX_ROWS_MAXL")) cap = std::min<uint64_t>(cap, strtoull(e, nullptr, 0));   // measurement override
+    const uint64_t steps[3] = {lcm_u64(P, 1024), lcm_u64(P, 32), lcm_u64(P, 4)};
     if (const char *e = getenv("DPX_ROWS_MULT")) {   // measurement override: L = mult * lcm(P, 4)
-        const uint64_t L = base * (uint64_t)atoi(e);
-        return (L >= base && L <= max_l) ? (uint32_t)L : 0;
+        const uint64_t L = steps[2] * (uint64_t)atoi(e);
+        return (L >= steps[2] && L <= cap) ? (uint32_t)L : 0;
     }
     uint32_t best = 0;
     double best_score = -1e9;
-    for (uint64_t L = base; L <= max_l && (L == base || L <= kRowsMultMaxL); L += base) {
-        double score = (double)L / (256.0 * (double)((L + 255) / 256));
-        if (L % 32 != 0) score -= 0.20;
-        if (L % 1024 != 0) score -= 0.03;
-        if (L > 1024) score -= 0.03 * log2((double)L / 1024.0) / 7.0;
-        if (score > best_score + 1e-9) { best_score = score; best = (uint32_t)L; }
+    for (uint64_t step : steps) {
+        int tried = 0;
+        for (uint64_t L = step; L <= cap && (L == step || L <= kRowsMultMaxL) && tried < 64; L += step, ++tried) {
+            double score = (double)L / (256.0 * (double)((L + 255) / 256));
+            if (L % 32 != 0) score -= 0.20;
+            if (L % 1024 != 0) score -= 0.03;
+            if (score > best_score + 1e-9) { best_score = score; best = (uint32_t)L; }
+        }
     }
     return best;
+}
+
+// rows per wavefront: 2 while one period of correctors stays L1/L2-hot, 4 for large tables
+// (measured, GB/s at R = 2 / 4 / 8: 8 KB table 6615 / 6264 / 6194; 876 KB table 5406 / 5660 / 5777)
+uint32_t pick_rows_per_wave(uint32_t P)
+{
+    uint32_t R = ((uint64_t)P + 3) * 8 <= (128u << 10) ? 2 : 4;
+    if (const char *e = getenv("DPX_ROWS_R")) R = (uint32_t)atoi(e);   // measurement override
+    return (R == 2 || R == 4 || R == 8) ? R : 2;
 }
 
 struct Interval { uint64_t lo, hi; };
@@ -171,50 +187,56 @@ void finalize(PlanResult &plan, uint32_t tile, bool use_rows)
     plan.launches.clear();
     const size_t ns = plan.segs.size();
     uint64_t pool = 0;
+    for (DevSeg &s : plan.segs) s.flags = 0;
 
     // ---- which stretches go to the rows kernel.  Each one is its own launch, so a plan with many
     // of them (track mode: one per second of stream) is better served by ONE tile-kernel launch over
     // everything (measured, 600 one-second stretches: 1.14 ms against 1.25 ms).
-    std::vector<Interval> covered;
-    size_t eligible = 0;
-    for (const DevSeg &s : plan.segs)
-        if (s.lut_len != 0 && s.count >= kRowsMinSamples && pick_row_length(s.period) != 0) ++eligible;
-    if (eligible > kRowsMaxLaunches) use_rows = false;
-    for (size_t i = 0; i < ns; ++i) {
-        DevSeg &s = plan.segs[i];
-        s.flags = 0;
-        if (!use_rows || s.lut_len == 0 || s.count < kRowsMinSamples) continue;
-        const uint32_t L = pick_row_length(s.period);
-        if (L == 0) continue;
+    auto rows_geometry = [&](const DevSeg &s, uint64_t *A, uint32_t *R, uint32_t *L) {
+        if (s.lut_len == 0 || s.count < kRowsMinSamples) return false;
         const uint64_t end = s.first + s.count;
         // matrix origin on a 256-sample boundary: 1 KiB of i16 / 2 KiB of f32 per wavefront, aligned
-        const uint64_t A = (s.first + 255) & ~255ull;
-        if (A >= end) continue;
-        // rows per wavefront: 2 while the table stays L1/L2-hot, 4 once it is large (measured, i16, GB/s at
-        // R = 2 / 4 / 8:  L = 1024: 6615 / 6264 / 6194;  L = 82 944: 6085 / 6243 / 6152;  L = 112 172: 5406 / 5660 / 5777)
-        uint32_t R = L <= 16384 ? 2 : 4;
-        if (const char *e = getenv("DPX_ROWS_R")) R = (uint32_t)atoi(e);   // measurement override
-        if (R != 2 && R != 4 && R != 8) R = 2;
+        *A = (s.first + 255) & ~255ull;
+        if (*A >= end) return false;
+        *R = pick_rows_per_wave(s.period);
+        *L = pick_row_length(s.period, end - *A, *R);
+        return *L != 0;
+    };
+    size_t eligible = 0;
+    for (const DevSeg &s : plan.segs) {
+        uint64_t A;
+        uint32_t R, L;
+        if (rows_geometry(s, &A, &R, &L)) ++eligible;
+    }
+    if (eligible > kRowsMaxLaunches) use_rows = false;
+    std::vector<Interval> covered;
+    std::vector<uint64_t> seg_covered_hi(ns, 0);     // per stretch: end of the part a rows launch covers (0 = none)
+    for (size_t i = 0; use_rows && i < ns; ++i) {
+        DevSeg &s = plan.segs[i];
+        uint64_t A;
+        uint32_t R, L;
+        if (!rows_geometry(s, &A, &R, &L)) continue;
+        const uint64_t end = s.first + s.count;
         const uint64_t n_rg = (end - A) / ((uint64_t)R * L);
-        if (n_rg < 16) continue;
-        s.flags |= kSegRows | kSegOwnsTable;
+        s.flags |= kSegRows;
         Launch ln;
         ln.kind = 0;
         ln.rows.A = A;
         ln.rows.B = A + n_rg * R * L;
         ln.rows.R = R;
-        ln.rows.pad = 0;
+        ln.rows.P = s.period;
         ln.rows.n_rg = n_rg;
         ln.rows.L = L;
         ln.rows.r0 = s.first;
-        ln.rows.r1 = end;
+        // a short tail is evaluated sample by sample by the launch's extra workgroups; a long one (up to R rows)
+        // is left to a tile-kernel launch
+        ln.rows.r1 = (end - ln.rows.B <= kAbsorbMax) ? end : ln.rows.B;
         ln.rows.seg_lo = (uint32_t)i;
         ln.rows.n_segs = (uint32_t)ns;
-        // table: L entries, origin = sample A
-        s.lut_off = (uint32_t)pool;
-        ln.rows.tab_off = s.lut_off;
-        plan.tables.push_back({pool, s.period, counter_at(s, A - s.first), L, s.ratio});
-        pool += ((uint64_t)L + 3) & ~3ull;
+        // table: one period (+3 so that four consecutive entries never wrap), origin = sample A
+        ln.rows.tab_off = (uint32_t)pool;
+        plan.tables.push_back({pool, s.period, counter_at(s, A - s.first), s.period + 3, s.ratio});
+        pool += ((uint64_t)s.period + 3 + 3) & ~3ull;
         plan.launches.push_back(ln);
     }
     // a rows launch also evaluates small neighbouring crumbs (e.g. the one-sample lead-in of a
@@ -222,7 +244,8 @@ void finalize(PlanResult &plan, uint32_t tile, bool use_rows)
     // stretch order, so "not below the previous launch's r1" keeps the ranges disjoint.
     uint64_t covered_hi = 0;
     for (Launch &ln : plan.launches) {
-        uint32_t lo = ln.rows.seg_lo;
+        const uint32_t own = ln.rows.seg_lo;
+        uint32_t lo = own;
         while (lo > 0) {
             const DevSeg &p = plan.segs[lo - 1];
             if ((p.flags & kSegRows) || p.first < covered_hi || ln.rows.A - p.first > kAbsorbMax) break;
@@ -230,24 +253,35 @@ void finalize(PlanResult &plan, uint32_t tile, bool use_rows)
         }
         ln.rows.seg_lo = lo;
         ln.rows.r0 = plan.segs[lo].first;
-        // seg_lo was the stretch itself before the walk; the following stretches start right after it
-        uint32_t hi = lo;
-        while (hi < ns && plan.segs[hi].first < ln.rows.r1) ++hi;
-        while (hi < ns) {
-            const DevSeg &q = plan.segs[hi];
-            if ((q.flags & kSegRows) || q.first + q.count - ln.rows.B > kAbsorbMax) break;
-            ln.rows.r1 = q.first + q.count;
-            ++hi;
+        const uint64_t own_end = plan.segs[own].first + plan.segs[own].count;
+        if (ln.rows.r1 == own_end) {                 // the whole tail is ours: following crumbs may join
+            uint32_t hi = own + 1;
+            while (hi < ns) {
+                const DevSeg &q = plan.segs[hi];
+                if ((q.flags & kSegRows) || q.first + q.count - ln.rows.B > kAbsorbMax) break;
+                ln.rows.r1 = q.first + q.count;
+                ++hi;
+            }
         }
+        seg_covered_hi[own] = std::min(ln.rows.r1, own_end);
         covered_hi = ln.rows.r1;
         covered.push_back({ln.rows.r0, ln.rows.r1});
     }
 
-    // ---- tables of the tabulated stretches that stay on the tile kernel
+    // ---- tile-kernel tables: every tabulated stretch with a part that no rows launch covers
     const DevSeg *prev = nullptr;   // same (ratio, period) shares a table
-    for (DevSeg &s : plan.segs) {
-        if (s.lut_len == 0 || (s.flags & kSegRows)) continue;
+    for (size_t i = 0; i < ns; ++i) {
+        DevSeg &s = plan.segs[i];
+        if (s.lut_len == 0) continue;
+        const uint64_t end = s.first + s.count;
+        bool needs_tile_table = !(s.flags & kSegRows) || seg_covered_hi[i] < end;
+        if (!(s.flags & kSegRows)) {                 // an absorbed crumb is evaluated per sample: no table
+            for (const Interval &c : covered)
+                if (c.lo <= s.first && end <= c.hi) needs_tile_table = false;
+        }
+        if (!needs_tile_table) continue;
         const uint32_t P = s.period;
+        s.flags |= kSegTileTable;
         s.c0 = (uint32_t)(((uint64_t)((s.n_start - 1u) % P) + P - (s.first % P)) % P);
         s.tmod = tile % P;
         if (prev && prev->period == P && memcmp(&prev->ratio, &s.ratio, sizeof(float)) == 0) {
@@ -255,7 +289,6 @@ void finalize(PlanResult &plan, uint32_t tile, bool use_rows)
             prev = &s;
             continue;
         }
-        s.flags |= kSegOwnsTable;
         prev = &s;
         s.lut_off = (uint32_t)pool;
         plan.tables.push_back({pool, P, 1u, P + tile, s.ratio});
@@ -318,7 +351,8 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
                 for (uint32_t row = 0; row < r.R; ++row)
                     for (uint32_t cs = 0; cs < r.L; ++cs) {
                         const uint64_t g = r.A + (rg * r.R + row) * (uint64_t)r.L + cs;
-                        put(g, (uint32_t)(((uint64_t)(tb->n_first - 1u) + cs) % tb->period) + 1u);
+                        const uint32_t e = (r.L == r.P) ? cs : cs % r.P;          // the kernel's table index
+                        put(g, (uint32_t)(((uint64_t)(tb->n_first - 1u) + e) % tb->period) + 1u);
                     }
             for (uint64_t g = r.r0; g < r.A; ++g) generic(r.seg_lo, g);
             for (uint64_t g = r.B; g < r.r1; ++g) generic(r.seg_lo, g);
@@ -332,7 +366,7 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
                 while (si + 1 < ns && plan.segs[si].first + plan.segs[si].count <= gs) ++si;
                 const DevSeg &sg = plan.segs[si];
                 const bool whole = in_mask && t0 >= sg.first && t0 + plan.tile <= sg.first + sg.count;
-                if (whole && sg.lut_len != 0 && !(sg.flags & kSegRows)) {
+                if (whole && sg.lut_len != 0 && (sg.flags & kSegTileTable)) {
                     const uint32_t P = sg.period;
                     uint32_t ph = P <= (1u << 18) ? sg.c0 + (((uint32_t)tile % P) * sg.tmod) % P
                                                   : sg.c0 + (uint32_t)(t0 % P);

@@ -9,13 +9,12 @@ namespace dpx {
 //   period == 0 ("linear"):   n = n_start + j            (no reset inside)
 //   period  > 0 ("periodic"): n = ((n_start - 1 + j) mod period) + 1
 // lut_len > 0 ("tabulated"): the correctors of one period (lut_len == period)
-// are precomputed.  How the table is laid out depends on which kernel serves
-// the stretch (flags):
-//   kSegRows:  rows kernel; table of RowsArgs::L entries starting at the phase of
-//              sample RowsArgs::A (no phase arithmetic in the kernel at all);
-//   otherwise: tile kernel; table of period + tile entries, entry e holding
-//              corrector((e mod period) + 1), indexed from the tile's phase
-//              (c0 + tile_index * tmod) mod period.
+// are precomputed, in up to two layouts (a stretch may have both):
+//   rows kernel (RowsArgs::tab_off): period + 3 entries starting at the phase of
+//              sample RowsArgs::A; index = column mod period, no phase arithmetic;
+//   tile kernel (kSegTileTable; lut_off, c0, tmod): period + tile entries, entry e
+//              holding corrector((e mod period) + 1), indexed from the tile's
+//              phase (c0 + tile_index * tmod) mod period.
 // lut_len == 0: sincos is evaluated per sample.
 struct DevSeg {
     uint64_t first;     // global sample index of the first sample
@@ -31,8 +30,8 @@ struct DevSeg {
 };
 static_assert(sizeof(DevSeg) == 48, "DevSeg is read with scalar loads");
 
-constexpr uint32_t kSegOwnsTable = 1u;   // this stretch's table must be built (not shared)
-constexpr uint32_t kSegRows = 2u;        // served by a rows-kernel launch
+constexpr uint32_t kSegRows = 2u;        // (most of) this stretch is served by a rows-kernel launch
+constexpr uint32_t kSegTileTable = 4u;   // lut_off / c0 / tmod describe a tile-kernel table
 
 // the first 32 bytes, as exposed through the C ABI (dpx_stretch)
 struct StretchView {
@@ -43,8 +42,8 @@ struct StretchView {
 
 constexpr int kSamplesPerLane = 4;          // tile kernel: one 16-byte i16 vector = 4 IQ samples
 constexpr uint32_t kLutMaxEntries = 4194304; // longest tile-kernel table (32 MiB: beyond L2, inside the 256 MiB Infinity Cache)
-constexpr uint32_t kRowsMaxL = 4194304;     // longest rows-kernel row / table (32 MiB, Infinity-Cache resident)
-constexpr uint32_t kRowsMultMaxL = 131072;  // multiples of lcm(P, 4) are only considered up to this row length
+constexpr uint32_t kRowsMaxL = 1u << 24;     // longest rows-kernel row, in samples (the table is one period whatever L)
+constexpr uint32_t kRowsMultMaxL = 131072;  // multiples of the basic row length are only considered up to this
 constexpr int kHintShift = 16;              // one stretch hint per 65536 samples
 constexpr int kRowsLanes = 64;              // rows kernel: one wavefront per workgroup
 
@@ -68,11 +67,11 @@ struct RowsArgs {
     uint64_t r0, r1;     // ragged ranges [r0, A) and [B, r1) handled by the extra workgroups
     uint64_t n_rg;       // row groups
     uint32_t L;          // row length in samples
-    uint32_t tab_off;    // table-pool entry index of the L-entry table (origin: sample A)
+    uint32_t tab_off;    // table-pool entry index of the (P + 3)-entry table (origin: sample A)
     uint32_t seg_lo;     // index of the stretch holding r0
     uint32_t n_segs;
     uint32_t R;          // rows per workgroup: 2, 4 or 8
-    uint32_t pad;
+    uint32_t P;          // period of the stretch (L is a multiple of it)
 };
 
 struct TileArgs {
