@@ -19,5 +19,5 @@ from ._lib import FMT_F32, FMT_I16, BUFFER_SIZE  # noqa: F401
 
 lib = _lib.load()
 
-from .engine import Context, Plan, Stream, DspError, default_context, plan_describe, plan_simulate  # noqa: E402,F401
+from .engine import Context, Plan, Stream, DspError, default_context, plan_describe, plan_simulate, plan_layout  # noqa: E402,F401
 from . import dsp  # noqa: E402,F401

@@ -26,6 +26,14 @@ class Stretch(C.Structure):
                 ("n_start", C.c_uint32), ("period", C.c_uint32), ("lut_len", C.c_uint32)]
 
 
+class Layout(C.Structure):
+    _fields_ = [("n_samples", C.c_uint64), ("rows_samples", C.c_uint64), ("walk_samples", C.c_uint64),
+                ("tile_samples", C.c_uint64), ("single_samples", C.c_uint64), ("table_entries", C.c_uint64),
+                ("n_stretches", C.c_uint32), ("rows_launches", C.c_uint32), ("tile_launches", C.c_uint32),
+                ("walk_launches", C.c_uint32), ("walk_matrices", C.c_uint32), ("walk_workgroups", C.c_uint32),
+                ("leftover_ranges", C.c_uint32), ("leftover_workgroups", C.c_uint32)]
+
+
 def declared_symbols():
     """Every function include/doppler_hip.h declares (parsed from the header text)."""
     with open(HEADER_PATH) as f:
@@ -54,6 +62,7 @@ _SIGNATURES = {
     "dpx_samplenum_after": (_i, [_f, _u32, _u32, _u64, _P(_u32)]),
     "dpx_plan_describe": (_i, [_P(Segment), _sz, _u32, _u32, _i, _P(Stretch), _sz, _P(_sz), _P(_u32)]),
     "dpx_plan_simulate": (_i, [_P(Segment), _sz, _u32, _u32, _i, _i, _i, _vp, _vp, _u64]),
+    "dpx_plan_layout": (_i, [_P(Segment), _sz, _u32, _u32, _i, _i, _i, _P(Layout)]),
     "dpx_track_schedule": (_i, [_vp, _sz, _u32, _u32, C.c_int32, _i, _i, _u64, _vp, _sz, _P(_sz)]),
     "dpx_orbit_observe": (_i, [C.c_char_p, C.c_char_p, C.c_double, C.c_double, C.c_double, C.c_double, _vp]),
     "dpx_orbit_propagate": (_i, [C.c_char_p, C.c_char_p, C.c_double, _vp]),

@@ -50,7 +50,7 @@ struct dpx_ctx {
     int block = 128;          // tile kernel: lanes per workgroup (128 or 256)
     int vecs = 2;             // tile kernel: 4-sample groups per lane (1 or 2); 128 x 2 measured best
     int variant = 0;
-    bool use_rows = true;     // false: tile kernel only (measurement A/B)
+    int choice = dpx::kChooseAuto;   // which kernels finalize() may use (dpx_set_tuning)
     hipStream_t stream = nullptr;   // internal stream of the host-pointer entry points
     void *stage_in = nullptr;
     void *stage_out = nullptr;
@@ -64,6 +64,11 @@ struct DevPlan {
     size_t cap = 0;
     dpx::DevSeg *segs = nullptr;
     uint32_t *hint = nullptr;
+    dpx::WalkSeg *walk = nullptr;
+    uint32_t *walk_hint = nullptr;
+    dpx::LeftRange *left = nullptr;
+    uint32_t *left_hint = nullptr;
+    void *sink = nullptr;          // where walk-kernel lanes without a sample store
     void *lut = nullptr;
 };
 
@@ -106,6 +111,13 @@ dpx::LaunchGeom geometry(const dpx_ctx *ctx)
     return g;
 }
 
+// dpx_set_tuning variants 4..6 restrict the kernels a plan may use (measurement A/B)
+inline int choice_of(int variant)
+{
+    return variant == 4 ? dpx::kChooseTileOnly : variant == 5 ? dpx::kChooseWalk : variant == 6 ? dpx::kChooseRows
+                                                                                                 : dpx::kChooseAuto;
+}
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // Upload stretch + hint tables and fill the corrector tables (async on `st`).
@@ -114,8 +126,13 @@ int materialize(dpx_ctx *ctx, const dpx::PlanResult &plan, DevPlan &dev, bool fm
 {
     const size_t seg_bytes = align256(plan.segs.size() * sizeof(dpx::DevSeg));
     const size_t hint_bytes = align256(plan.hint.size() * sizeof(uint32_t));
+    const size_t walk_bytes = align256(plan.walk.size() * sizeof(dpx::WalkSeg));
+    const size_t whint_bytes = align256(plan.walk_hint.size() * sizeof(uint32_t));
+    const size_t left_bytes = align256(plan.left.size() * sizeof(dpx::LeftRange));
+    const size_t lhint_bytes = align256(plan.left_hint.size() * sizeof(uint32_t));
     const size_t lut_bytes = align256(plan.lut_entries * 8 + 64);
-    const size_t need = seg_bytes + hint_bytes + lut_bytes;
+    const size_t sink_bytes = align256(dpx::kWalkSinkBytes);
+    const size_t need = seg_bytes + hint_bytes + walk_bytes + whint_bytes + left_bytes + lhint_bytes + sink_bytes + lut_bytes;
     if (need > dev.cap) {
         if (dev.buf) {
             DPX_HIP(hipStreamSynchronize(st));
@@ -130,7 +147,23 @@ int materialize(dpx_ctx *ctx, const dpx::PlanResult &plan, DevPlan &dev, bool fm
     char *base = static_cast<char *>(dev.buf);
     dev.segs = reinterpret_cast<dpx::DevSeg *>(base);
     dev.hint = reinterpret_cast<uint32_t *>(base + seg_bytes);
-    dev.lut = base + seg_bytes + hint_bytes;
+    char *p = base + seg_bytes + hint_bytes;
+    dev.walk = reinterpret_cast<dpx::WalkSeg *>(p);          p += walk_bytes;
+    dev.walk_hint = reinterpret_cast<uint32_t *>(p);         p += whint_bytes;
+    dev.left = reinterpret_cast<dpx::LeftRange *>(p);        p += left_bytes;
+    dev.left_hint = reinterpret_cast<uint32_t *>(p);         p += lhint_bytes;
+    dev.sink = p;                                            p += sink_bytes;
+    dev.lut = p;
+    if (!plan.walk.empty()) {
+        DPX_HIP(hipMemcpyAsync(dev.walk, plan.walk.data(), plan.walk.size() * sizeof(dpx::WalkSeg),
+                               hipMemcpyHostToDevice, st));
+        DPX_HIP(hipMemcpyAsync(dev.walk_hint, plan.walk_hint.data(), plan.walk_hint.size() * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, st));
+        DPX_HIP(hipMemcpyAsync(dev.left, plan.left.data(), plan.left.size() * sizeof(dpx::LeftRange),
+                               hipMemcpyHostToDevice, st));
+        DPX_HIP(hipMemcpyAsync(dev.left_hint, plan.left_hint.data(), plan.left_hint.size() * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, st));
+    }
     DPX_HIP(hipMemcpyAsync(dev.segs, plan.segs.data(), plan.segs.size() * sizeof(dpx::DevSeg),
                            hipMemcpyHostToDevice, st));
     DPX_HIP(hipMemcpyAsync(dev.hint, plan.hint.data(), plan.hint.size() * sizeof(uint32_t),
@@ -151,6 +184,9 @@ int run_plan(const dpx::PlanResult &plan, const DevPlan &dev, const void *d_in, 
         int rc;
         if (ln.kind == 0)
             rc = dpx::launch_rows(d_in, in_fmt, d_out, out_fmt, dev.segs, dev.lut, ln.rows, fma, st);
+        else if (ln.kind == 2)
+            rc = dpx::launch_walk(d_in, in_fmt, d_out, out_fmt, dev.segs, dev.lut, dev.walk, dev.walk_hint, dev.left,
+                                  dev.left_hint, dev.sink, ln.walk, fma, st);
         else
             rc = dpx::launch_tiles(d_in, in_fmt, d_out, out_fmt, dev.segs, (uint32_t)plan.segs.size(), dev.hint,
                                    dev.lut, ln.tiles, fma, g, st);
@@ -178,7 +214,7 @@ int run_host(dpx_ctx *ctx, const void *in, size_t n, int in_fmt, void *out, int 
         return DPX_OK;
     }
     const dpx::LaunchGeom g = geometry(ctx);
-    dpx::finalize(plan, g.tile(), ctx->use_rows);
+    dpx::finalize(plan, g.tile(), ctx->choice);
     if (plan.error) return fail(DPX_ERR_PLAN, "%s", plan.error);
     const size_t in_bytes = n * bytes_per_sample(in_fmt), out_bytes = n * bytes_per_sample(out_fmt);
     int rc = ensure_stage(ctx, in_bytes, out_bytes);
@@ -266,11 +302,11 @@ int dpx_set_tuning(dpx_ctx *ctx, int block, int vecs, int variant)
     if (!ctx) return fail(DPX_ERR_ARG, "ctx is null");
     if (block != 0 && block != 128 && block != 256) return fail(DPX_ERR_ARG, "block must be 128 or 256");
     if (vecs != 0 && vecs != 1 && vecs != 2) return fail(DPX_ERR_ARG, "vecs must be 1 or 2");
-    if (variant < 0 || variant > 4) return fail(DPX_ERR_ARG, "variant out of range");
+    if (variant < 0 || variant > 6) return fail(DPX_ERR_ARG, "variant out of range");
     if (block) ctx->block = block;
     if (vecs) ctx->vecs = vecs;
-    ctx->use_rows = variant != 4;
-    ctx->variant = (variant == 3 || variant == 4) ? 0 : variant;
+    ctx->choice = choice_of(variant);
+    ctx->variant = variant >= 3 ? 0 : variant;
     return DPX_OK;
 }
 
@@ -433,7 +469,7 @@ int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
     if ((n_segs && !segs) || !counters || !writes) return fail(DPX_ERR_ARG, "bad argument");
     dpx::PlanResult plan;
     uint32_t sn = samplenum0;
-    const int v = (variant == 3 || variant == 4) ? 0 : variant;
+    const int v = variant >= 3 ? 0 : variant;
     for (size_t i = 0; i < n_segs; ++i)
         dpx::plan_append(plan, dpx::ratio_of(segs[i].shift_hz, samplerate), segs[i].n_samples, sn, v);
     if (plan.n_samples != n_samples) return fail(DPX_ERR_PLAN, "segments hold %llu samples, buffers %llu",
@@ -441,9 +477,50 @@ int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
     dpx::LaunchGeom g;
     g.block = block ? block : 128;
     g.vecs = vecs ? vecs : 2;
-    dpx::finalize(plan, g.tile(), variant != 4);
+    dpx::finalize(plan, g.tile(), choice_of(variant));
     memset(writes, 0, n_samples);
     dpx::simulate(plan, counters, writes);
+    return DPX_OK;
+}
+
+int dpx_plan_layout(const dpx_segment *segs, size_t n_segs, uint32_t samplerate, uint32_t samplenum0,
+                    int block, int vecs, int variant, dpx_layout *out)
+{
+    if ((n_segs && !segs) || !out) return fail(DPX_ERR_ARG, "bad argument");
+    dpx::PlanResult plan;
+    uint32_t sn = samplenum0;
+    const int v = variant >= 3 ? 0 : variant;
+    for (size_t i = 0; i < n_segs; ++i)
+        dpx::plan_append(plan, dpx::ratio_of(segs[i].shift_hz, samplerate), segs[i].n_samples, sn, v);
+    dpx::LaunchGeom g;
+    g.block = block ? block : 128;
+    g.vecs = vecs ? vecs : 2;
+    dpx::finalize(plan, g.tile(), choice_of(variant));
+    if (plan.error) return fail(DPX_ERR_PLAN, "%s", plan.error);
+    memset(out, 0, sizeof *out);
+    out->n_samples = plan.n_samples;
+    out->n_stretches = (uint32_t)plan.segs.size();
+    out->table_entries = plan.lut_entries;
+    for (const dpx::Launch &ln : plan.launches) {
+        if (ln.kind == 0) {
+            ++out->rows_launches;
+            out->rows_samples += ln.rows.B - ln.rows.A;
+            out->single_samples += (ln.rows.A - ln.rows.r0) + (ln.rows.r1 - ln.rows.B);
+        } else if (ln.kind == 1) {
+            ++out->tile_launches;
+            out->tile_samples += ln.tiles.m1 - ln.tiles.m0;
+        } else {
+            ++out->walk_launches;
+            out->walk_workgroups = ln.walk.n_walk_wg;
+            out->leftover_workgroups = ln.walk.n_left_wg;
+        }
+    }
+    if (!plan.walk.empty()) {
+        out->walk_matrices = (uint32_t)plan.walk.size() - 1;
+        out->leftover_ranges = (uint32_t)plan.left.size() - 1;
+        for (size_t i = 0; i + 1 < plan.walk.size(); ++i) out->walk_samples += plan.walk[i].E - plan.walk[i].A;
+        for (size_t i = 0; i + 1 < plan.left.size(); ++i) out->single_samples += plan.left[i].len;
+    }
     return DPX_OK;
 }
 
@@ -526,7 +603,7 @@ int dpx_plan_segments(dpx_ctx *ctx, const dpx_segment *segs, size_t n_segs, uint
     for (size_t i = 0; i < n_segs; ++i)
         dpx::plan_append(p->host, dpx::ratio_of(segs[i].shift_hz, samplerate), segs[i].n_samples, sn,
                          ctx->variant);
-    dpx::finalize(p->host, p->geom.tile(), ctx->use_rows);
+    dpx::finalize(p->host, p->geom.tile(), ctx->choice);
     hipError_t e = hipSetDevice(ctx->device);
     int rc = e == hipSuccess ? DPX_OK : fail(DPX_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
     if (rc == DPX_OK && p->host.error) rc = fail(DPX_ERR_PLAN, "%s", p->host.error);
@@ -701,7 +778,7 @@ int dpx_stream_submit(dpx_stream *s, size_t in_bytes, const dpx_segment *segs, s
     for (size_t i = 0; i < n_segs; ++i)
         dpx::plan_append(b.plan, dpx::ratio_of(segs[i].shift_hz, s->samplerate), segs[i].n_samples, sn, ctx->variant);
     const dpx::LaunchGeom g = geometry(ctx);
-    dpx::finalize(b.plan, g.tile(), ctx->use_rows);
+    dpx::finalize(b.plan, g.tile(), ctx->choice);
     if (b.plan.error) return fail(DPX_ERR_PLAN, "%s", b.plan.error);
     b.out_bytes = (size_t)total * obs;
     if (total) {

@@ -13,6 +13,7 @@
 // dpx_types.h (DevSeg), so every sample's corrector depends only on its index.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/doppler_hip.h"
 #include "dpx_sincos.cuh"
@@ -366,6 +367,163 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
     }
 }
 
+
+// ---- walk kernel: many tabulated stretches in one launch (dpx_types.h, WalkSeg).
+// A workgroup = 4 wavefronts x 2 rows of ONE 256-sample column window: the window's correctors (288 table entries,
+// whatever the rows' shifts) are read from memory once, staged in LDS, and used by all eight rows.  One shot, no loop,
+// no divergent branch: the compiler serialises loads that sit in divergent blocks, so a lane without a sample
+// (past the end of its row, or a row past the end of the matrix) loads from the start of the matrix instead and
+// stores to a scratch area (`sink`).
+template <int IN_FMT, int OUT_FMT, bool FMA, int WAVES, int U>
+__global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restrict__ in,
+                                                            uint8_t *__restrict__ out,
+                                                            const float2 *__restrict__ lut_pool,
+                                                            const WalkSeg *__restrict__ wsegs,
+                                                            const uint32_t *__restrict__ whint,
+                                                            uint32_t n_walk_wg,
+                                                            uint8_t *__restrict__ sink,
+                                                            // ---- leftover path only
+                                                            const LeftRange *__restrict__ left,
+                                                            const uint32_t *__restrict__ lhint,
+                                                            const DevSeg *__restrict__ segs)
+{
+    constexpr int S = RowVec<IN_FMT, OUT_FMT>::S;                 // samples per lane per vector: 4 or 2
+    constexpr int NV = (int)kWalkWindow / (kRowsLanes * S);       // vectors per lane per row: 1 or 2
+    constexpr int THREADS = WAVES * 64;
+    constexpr int IB = Fmt<IN_FMT>::kBytes, OB = Fmt<OUT_FMT>::kBytes;
+    constexpr int QW = S * IB / 4;                                // input dwords per vector
+    typedef uint32_t qvec __attribute__((ext_vector_type(QW)));
+    __shared__ float2 slice[kWalkSlice];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+
+    if (b < n_walk_wg) {
+        const uint32_t lane = tid & (kRowsLanes - 1), wave = tid / kRowsLanes;
+        uint32_t wi = whint[b >> kWalkHintShift];
+        while (wsegs[wi + 1].wg_base <= b) ++wi;                  // the list ends with a sentinel
+        const WalkSeg ws = wsegs[wi];
+        // workgroups of a stretch: row chunk major, window fastest (a chunk sweeps its rows contiguously), the window
+        // count padded to a multiple of 8: workgroup ids that differ by a multiple of 8 run on the same XCD, so all
+        // the chunks of one window find its table slice in that XCD's L2
+        const uint32_t q = b - ws.wg_base;
+        const uint32_t nw8 = (ws.nw + 7u) & ~7u;
+        const uint32_t chunk = (uint32_t)(((uint64_t)q * ws.div_m) >> ws.div_s);   // q / nw8
+        const uint32_t w = q - chunk * nw8;
+        if (w >= ws.nw) return;                                   // padding
+
+        // this window's slice of the table: entry j = corrector of column 256 w + j - kWalkPad
+        const float2 *tab = lut_pool + ws.tab_off + w * kWalkWindow;
+        constexpr int TL = ((int)kWalkSlice / 2 + THREADS - 1) / THREADS;   // 16-byte pieces per thread: 1 (2 for 128 threads)
+        float2 t0[TL], t1[TL];
+#pragma unroll
+        for (int i = 0; i < TL; ++i) {
+            const uint32_t j = tid + (uint32_t)i * THREADS;
+            if (j < kWalkSlice / 2) {
+                t0[i] = tab[2 * j];
+                t1[i] = tab[2 * j + 1];
+            }
+        }
+
+        const uint32_t r0 = chunk * (WAVES * U) + wave * U;
+        qvec qin[U][NV];
+        uint32_t li[U][NV];                                       // index into the slice
+        uint8_t *op[U][NV];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool valid = r0 + u < ws.rows;
+            const uint64_t ideal = ws.A + (uint64_t)(valid ? r0 + u : 0u) * ws.L;
+            const uint64_t row0 = ideal & ~31ull;                             // whole 128-byte lines on both sides
+            const uint32_t delta = (uint32_t)ideal & 31u;
+            const uint64_t nxt = (ideal + ws.L) & ~31ull;
+            const uint32_t rowlen = valid ? (uint32_t)((nxt < ws.E ? nxt : ws.E) - row0) : 0u;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const uint32_t cl = lane * S + (uint32_t)v * (kRowsLanes * S);   // column inside the window
+                const uint32_t c = w * kWalkWindow + cl;
+                const bool active = c < rowlen;
+                const uint64_t g = active ? row0 + c : ws.A + cl;
+                qin[u][v] = __builtin_nontemporal_load(reinterpret_cast<const qvec *>(in + g * IB));
+                li[u][v] = kWalkPad - delta + cl;
+                op[u][v] = active ? out + g * OB : sink + tid * 16;
+            }
+        }
+
+#pragma unroll
+        for (int i = 0; i < TL; ++i) {
+            const uint32_t j = tid + (uint32_t)i * THREADS;
+            if (j < kWalkSlice / 2) {
+                slice[2 * j] = t0[i];
+                slice[2 * j + 1] = t1[i];
+            }
+        }
+        __syncthreads();
+        if (r0 >= ws.rows) return;                                // a wavefront past the last row (uniform)
+
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float re[S], im[S];
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    const float2 cs = slice[li[u][v] + k];
+                    float a, bq;
+                    if constexpr (IN_FMT == DPX_FMT_I16) unpack_i16(qin[u][v][k], a, bq);
+                    else { a = __uint_as_float(qin[u][v][2 * k]); bq = __uint_as_float(qin[u][v][2 * k + 1]); }
+                    mix(a, bq, cs.x, cs.y, re[k], im[k]);
+                }
+                if constexpr (OUT_FMT == DPX_FMT_I16) {
+                    if constexpr (S == 4) {
+                        u32x4 o = {pack_i16(re[0], im[0]), pack_i16(re[1], im[1]), pack_i16(re[2], im[2]),
+                                   pack_i16(re[3], im[3])};
+                        asm volatile("" : "+v"(o));   // keeps the vectoriser from rebuilding the store without its nt flag
+                        __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(op[u][v]));
+                    } else {
+                        u32x2 o;
+                        o[0] = pack_i16(re[0], im[0]);
+                        o[1] = pack_i16(re[1], im[1]);
+                        __builtin_nontemporal_store(o, reinterpret_cast<u32x2 *>(op[u][v]));
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < S / 2; ++i) {
+                        u32x4 o;
+                        o[0] = __float_as_uint(re[2 * i]);     o[1] = __float_as_uint(im[2 * i]);
+                        o[2] = __float_as_uint(re[2 * i + 1]); o[3] = __float_as_uint(im[2 * i + 1]);
+                        __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(op[u][v]) + i);
+                    }
+                }
+            }
+        }
+    } else {
+        // ---- leftover ranges: one block of kLeftBlock samples of ONE stretch, sincos per sample
+        const uint32_t e = b - n_walk_wg;
+        uint32_t li = lhint[e >> kLeftHintShift];
+        while (left[li + 1].wg_off <= e) ++li;                    // sentinel at the end
+        const LeftRange lr = left[li];
+        const DevSeg sg = segs[lr.seg];
+        const uint32_t o0 = (e - lr.wg_off) * kLeftBlock;         // offset of this block in the range
+        const uint64_t g0 = lr.start + o0;
+        const uint32_t P = sg.period;
+        const uint64_t j0 = g0 - sg.first;
+        uint32_t base;   // periodic: phase of g0 in [0, P); linear: the counter itself
+        if (P != 0) base = (uint32_t)(((uint64_t)(sg.n_start - 1u) + j0) % P);
+        else        base = sg.n_start + (uint32_t)j0;
+#pragma unroll 1
+        for (uint32_t k = 0; k < kLeftBlock / THREADS; ++k) {
+            const uint32_t o = k * THREADS + tid;
+            if (o0 + o >= lr.len) break;
+            uint32_t n;
+            if (P != 0) n = (uint32_t)(((uint64_t)base + o) % P) + 1u;
+            else        n = base + o;
+            float c, s, a, bq, re, im;
+            corrector<FMA>(sg.ratio, n, c, s);
+            load_one<IN_FMT>(in, g0 + o, a, bq);
+            mix(a, bq, c, s, re, im);
+            store_one<OUT_FMT>(out, g0 + o, re, im);
+        }
+    }
+}
+
 // plan-time: entry e of a table = corrector(((n_first - 1 + e) mod period) + 1)
 template <bool FMA>
 __global__ __launch_bounds__(256) void build_lut_kernel(float2 *__restrict__ tab, uint32_t period,
@@ -512,6 +670,38 @@ int launch_rows(const void *d_in, int in_fmt, void *d_out, int out_fmt, const De
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     DPX_DISPATCH_FMT(rows_t, d_in, d_out, d_segs, d_lut, r, fma, st);
+}
+
+template <int IN_FMT, int OUT_FMT>
+static int walk_t(const void *d_in, void *d_out, const DevSeg *d_segs, const void *d_lut, const WalkSeg *d_walk,
+                  const uint32_t *d_whint, const LeftRange *d_left, const uint32_t *d_lhint, void *d_sink,
+                  const WalkArgs &w, bool fma, hipStream_t st)
+{
+    const uint8_t *in = static_cast<const uint8_t *>(d_in);
+    uint8_t *out = static_cast<uint8_t *>(d_out);
+    uint8_t *sink = static_cast<uint8_t *>(d_sink);
+    const float2 *lut = static_cast<const float2 *>(d_lut);
+    const uint64_t n_wg = (uint64_t)w.n_walk_wg + w.n_left_wg;
+    if (n_wg == 0) return DPX_OK;
+    if (n_wg > 0x7fffffffull) return DPX_ERR_ARG;
+    const dim3 grid((uint32_t)n_wg);
+#define DPX_WALK_CASE(WW, UU)                                                                                                              \
+    if (w.waves == WW && w.rows_per_wave == UU) {                                                                                         \
+        if (fma) walk_kernel<IN_FMT, OUT_FMT, true, WW, UU><<<grid, WW * 64, 0, st>>>(in, out, lut, d_walk, d_whint, w.n_walk_wg, sink, d_left, d_lhint, d_segs);  \
+        else     walk_kernel<IN_FMT, OUT_FMT, false, WW, UU><<<grid, WW * 64, 0, st>>>(in, out, lut, d_walk, d_whint, w.n_walk_wg, sink, d_left, d_lhint, d_segs); \
+        return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                                                    \
+    }
+    DPX_WALK_CASE(4, 2) DPX_WALK_CASE(4, 4) DPX_WALK_CASE(8, 2) DPX_WALK_CASE(4, 1) DPX_WALK_CASE(8, 1) DPX_WALK_CASE(2, 2) DPX_WALK_CASE(2, 4)
+#undef DPX_WALK_CASE
+    return DPX_ERR_ARG;
+}
+
+int launch_walk(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs, const void *d_lut,
+                const WalkSeg *d_walk, const uint32_t *d_walk_hint, const LeftRange *d_left,
+                const uint32_t *d_left_hint, void *d_sink, const WalkArgs &w, bool fma, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DPX_DISPATCH_FMT(walk_t, d_in, d_out, d_segs, d_lut, d_walk, d_walk_hint, d_left, d_left_hint, d_sink, w, fma, st);
 }
 
 int launch_build_lut(void *d_lut_entries, uint32_t period, uint32_t n_first, uint32_t n_entries,

@@ -5,6 +5,7 @@
 
 #include <math.h>
 #include <string.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -177,21 +178,83 @@ uint32_t pick_rows_per_wave(uint32_t P)
 
 struct Interval { uint64_t lo, hi; };
 
+constexpr uint64_t kWalkTileMin = 1u << 16;      // an uncovered gap at least this long gets its own tile launch ...
+constexpr size_t kWalkMaxTileLaunches = 8;       // ... up to this many; the rest is evaluated by leftover workgroups
+
+struct WalkShape { uint32_t waves, rows_per_wave; };
+WalkShape walk_shape()
+{
+    static const WalkShape shape = [] {
+        WalkShape g = {kWalkWaves, kWalkRowsPerWave};
+        if (const char *e = getenv("DPX_WALK_SHAPE")) {             // measurement override: "waves,rows"
+            int a = 0, b = 0;
+            if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) g = {(uint32_t)a, (uint32_t)b};
+        }
+        return g;
+    }();
+    return shape;
+}
+
+// matrix of the walk kernel for one stretch (dpx_types.h, WalkSeg); false if the stretch does not qualify
+bool walk_geometry(const DevSeg &s, WalkSeg *w)
+{
+    const WalkShape shape = walk_shape();
+    if (s.lut_len == 0 || s.period == 0) return false;
+    const uint64_t end = s.first + s.count;
+    const uint64_t A = (s.first + 31) & ~31ull, E = end & ~31ull;
+    if (E <= A) return false;
+    const uint64_t P = s.period;
+    const uint64_t L = P >= kWalkMinL ? P : P * ((kWalkMinL + P - 1) / P);
+    if (L > kLutMaxEntries || E - A < 2 * L) return false;     // the table must be reused at least once
+    const uint64_t rows = (E - A + L - 1) / L;
+    const uint64_t longest = (L % 32 == 0) ? L : (L & ~31ull) + 32;   // rows start on 32-sample boundaries
+    const uint64_t nw = (longest + kWalkWindow - 1) / kWalkWindow;
+    if (rows > 0xffffffffull) return false;
+    w->A = A;
+    w->E = E;
+    w->L = (uint32_t)L;
+    w->tab_off = 0;
+    w->wg_base = 0;
+    w->nw = (uint32_t)nw;
+    w->rows = (uint32_t)rows;
+    const uint64_t rpw = shape.waves * shape.rows_per_wave;
+    const uint64_t n_chunks = (rows + rpw - 1) / rpw;
+    if (n_chunks > 0x0fffffffull) return false;
+    w->n_chunks = (uint32_t)n_chunks;
+    // exact q / d for q < 2^31, d = nw padded to a multiple of 8: M = ceil(2^(31+s) / d), s = ceil(log2 d)
+    const uint64_t d = (nw + 7) & ~7ull;
+    uint32_t sh = 0;
+    while ((1ull << sh) < d) ++sh;
+    w->div_s = 31 + sh;
+    w->div_m = (uint32_t)(((1ull << w->div_s) + d - 1) / d);
+    return true;
+}
+
+uint64_t walk_workgroups(const WalkSeg &w)
+{
+    return (uint64_t)((w.nw + 7) / 8) * 8 * w.n_chunks;     // groups of 8 windows x n_chunks, the last group padded
+}
+
 }  // namespace
 
-void finalize(PlanResult &plan, uint32_t tile, bool use_rows)
+void finalize(PlanResult &plan, uint32_t tile, int choice)
 {
     plan.tile = tile;
     plan.error = nullptr;
     plan.tables.clear();
     plan.launches.clear();
+    plan.walk.clear();
+    plan.walk_hint.clear();
+    plan.left.clear();
+    plan.left_hint.clear();
     const size_t ns = plan.segs.size();
     uint64_t pool = 0;
     for (DevSeg &s : plan.segs) s.flags = 0;
 
-    // ---- which stretches go to the rows kernel.  Each one is its own launch, so a plan with many
-    // of them (track mode: one per second of stream) is better served by ONE tile-kernel launch over
-    // everything (measured, 600 one-second stretches: 1.14 ms against 1.25 ms).
+    // ---- which kernel serves the tabulated stretches.
+    // rows kernel: one launch per stretch, the fastest shape for a long stretch (const mode);
+    // walk kernel: any number of stretches in one launch (track mode: one stretch per second of stream);
+    // tile kernel: whatever is left, and everything when neither of the above applies.
     auto rows_geometry = [&](const DevSeg &s, uint64_t *A, uint32_t *R, uint32_t *L) {
         if (s.lut_len == 0 || s.count < kRowsMinSamples) return false;
         const uint64_t end = s.first + s.count;
@@ -202,14 +265,29 @@ void finalize(PlanResult &plan, uint32_t tile, bool use_rows)
         *L = pick_row_length(s.period, end - *A, *R);
         return *L != 0;
     };
-    size_t eligible = 0;
-    for (const DevSeg &s : plan.segs) {
-        uint64_t A;
-        uint32_t R, L;
-        if (rows_geometry(s, &A, &R, &L)) ++eligible;
+    bool use_rows = false, use_walk = false;
+    if (choice == kChooseAuto || choice == kChooseRows) {
+        size_t eligible = 0;
+        for (const DevSeg &s : plan.segs) {
+            uint64_t A;
+            uint32_t R, L;
+            if (rows_geometry(s, &A, &R, &L)) ++eligible;
+        }
+        use_rows = eligible > 0 && eligible <= kRowsMaxLaunches;
     }
-    if (eligible > kRowsMaxLaunches) use_rows = false;
-    std::vector<Interval> covered;
+    if ((choice == kChooseAuto && !use_rows) || choice == kChooseWalk) {
+        uint64_t in_matrices = 0, n_wg = 0;
+        for (const DevSeg &s : plan.segs) {
+            WalkSeg w;
+            if (!walk_geometry(s, &w)) continue;
+            in_matrices += w.E - w.A;
+            n_wg += walk_workgroups(w);
+        }
+        // worth it when most of the stream is in matrices (the rest is evaluated sample by sample)
+        use_walk = in_matrices > 0 && in_matrices >= plan.n_samples / 2 && n_wg < 0x40000000ull;
+    }
+
+    std::vector<Interval> covered;                   // what rows launches / walk matrices produce, in stream order
     std::vector<uint64_t> seg_covered_hi(ns, 0);     // per stretch: end of the part a rows launch covers (0 = none)
     for (size_t i = 0; use_rows && i < ns; ++i) {
         DevSeg &s = plan.segs[i];
@@ -268,16 +346,121 @@ void finalize(PlanResult &plan, uint32_t tile, bool use_rows)
         covered.push_back({ln.rows.r0, ln.rows.r1});
     }
 
-    // ---- tile-kernel tables: every tabulated stretch with a part that no rows launch covers
+    // ---- walk matrices, and the pieces of the stream they leave out
+    struct Piece { uint64_t lo, hi; uint32_t seg; };
+    std::vector<Piece> pieces;
+    if (use_walk) {
+        uint64_t wg = 0;
+        for (size_t i = 0; i < ns; ++i) {
+            DevSeg &s = plan.segs[i];
+            const uint64_t end = s.first + s.count;
+            WalkSeg w;
+            if (!walk_geometry(s, &w)) {
+                pieces.push_back({s.first, end, (uint32_t)i});
+                continue;
+            }
+            s.flags |= kSegWalk;
+            w.wg_base = (uint32_t)wg;
+            w.tab_off = (uint32_t)pool;
+            wg += walk_workgroups(w);
+            // entry x = corrector of column x - kWalkPad, column 0 = sample A
+            const uint32_t P = s.period;
+            const uint32_t phase_a = counter_at(s, w.A - s.first) - 1u;
+            const uint32_t n_first = (uint32_t)(((uint64_t)phase_a + (uint64_t)P * kWalkPad - kWalkPad) % P) + 1u;
+            const uint32_t n_entries = w.nw * kWalkWindow + kWalkPad;     // every window reads a whole 288-entry slice
+            plan.tables.push_back({pool, P, n_first, n_entries, s.ratio});
+            pool += ((uint64_t)n_entries + 3) & ~3ull;
+            plan.walk.push_back(w);
+            if (s.first < w.A) pieces.push_back({s.first, w.A, (uint32_t)i});
+            if (w.E < end) pieces.push_back({w.E, end, (uint32_t)i});
+            covered.push_back({w.A, w.E});
+        }
+        // uncovered pieces that touch form a gap; long gaps become tile launches, the rest leftover ranges
+        std::vector<Interval> gaps_for_tiles;
+        uint64_t left_wg = 0;
+        for (size_t i = 0; i < pieces.size();) {
+            size_t j = i + 1;
+            while (j < pieces.size() && pieces[j].lo == pieces[j - 1].hi) ++j;
+            const uint64_t lo = pieces[i].lo, hi = pieces[j - 1].hi;
+            if (hi - lo >= kWalkTileMin && gaps_for_tiles.size() < kWalkMaxTileLaunches) {
+                gaps_for_tiles.push_back({lo, hi});
+            } else {
+                for (size_t k = i; k < j; ++k) {
+                    for (uint64_t p0 = pieces[k].lo; p0 < pieces[k].hi;) {
+                        const uint64_t len = std::min<uint64_t>(pieces[k].hi - p0, 1u << 30);
+                        plan.left.push_back({p0, (uint32_t)len, pieces[k].seg, (uint32_t)left_wg, 0});
+                        left_wg += (len + kLeftBlock - 1) / kLeftBlock;
+                        p0 += len;
+                    }
+                    covered.push_back({pieces[k].lo, pieces[k].hi});
+                }
+            }
+            i = j;
+        }
+        if (wg + left_wg > 0x7fffffffull) plan.error = "stream needs more than 2^31 workgroups";
+        Launch ln;
+        ln.kind = 2;
+        ln.walk.n_walk_wg = (uint32_t)wg;
+        ln.walk.n_left_wg = (uint32_t)left_wg;
+        ln.walk.n_segs = (uint32_t)ns;
+        ln.walk.waves = walk_shape().waves;
+        ln.walk.rows_per_wave = walk_shape().rows_per_wave;
+        plan.launches.push_back(ln);
+        // sentinels end the kernels' forward scans; hints give the scan its starting point
+        WalkSeg wend;
+        memset(&wend, 0, sizeof wend);
+        wend.wg_base = 0xffffffffu;
+        plan.walk.push_back(wend);
+        plan.left.push_back({0, 0, 0, 0xffffffffu, 0});
+        const uint64_t n_wh = (wg >> kWalkHintShift) + 1;
+        plan.walk_hint.assign(n_wh, 0);
+        uint32_t wi = 0;
+        for (uint64_t h = 0; h < n_wh; ++h) {
+            while (plan.walk[wi + 1].wg_base <= (h << kWalkHintShift)) ++wi;
+            plan.walk_hint[h] = wi;
+        }
+        const uint64_t n_lh = (left_wg >> kLeftHintShift) + 1;
+        plan.left_hint.assign(n_lh, 0);
+        uint32_t li = 0;
+        for (uint64_t h = 0; h < n_lh; ++h) {
+            while (plan.left[li + 1].wg_off <= (h << kLeftHintShift)) ++li;
+            plan.left_hint[h] = li;
+        }
+    }
+
+    // ---- everything nothing above covers goes to tile-kernel launches
+    std::sort(covered.begin(), covered.end(), [](const Interval &a, const Interval &b) { return a.lo < b.lo; });
+    std::vector<Interval> tile_ranges;
+    uint64_t pos = 0;
+    auto add_tiles = [&](uint64_t lo, uint64_t hi) {
+        if (lo >= hi) return;
+        Launch ln;
+        ln.kind = 1;
+        ln.tiles.m0 = lo;
+        ln.tiles.m1 = hi;
+        ln.tiles.tile_lo = lo / tile;
+        ln.tiles.n_tiles = (hi + tile - 1) / tile - ln.tiles.tile_lo;
+        plan.launches.push_back(ln);
+        tile_ranges.push_back({lo, hi});
+    };
+    for (const Interval &c : covered) {
+        add_tiles(pos, c.lo);
+        pos = std::max(pos, c.hi);
+    }
+    add_tiles(pos, plan.n_samples);
+
+    // ---- tile-kernel tables: every tabulated stretch with at least a tile's worth of samples in a tile launch
     const DevSeg *prev = nullptr;   // same (ratio, period) shares a table
+    size_t tr = 0;
     for (size_t i = 0; i < ns; ++i) {
         DevSeg &s = plan.segs[i];
         if (s.lut_len == 0) continue;
         const uint64_t end = s.first + s.count;
-        bool needs_tile_table = !(s.flags & kSegRows) || seg_covered_hi[i] < end;
-        if (!(s.flags & kSegRows)) {                 // an absorbed crumb is evaluated per sample: no table
-            for (const Interval &c : covered)
-                if (c.lo <= s.first && end <= c.hi) needs_tile_table = false;
+        while (tr < tile_ranges.size() && tile_ranges[tr].hi <= s.first) ++tr;
+        bool needs_tile_table = false;
+        for (size_t k = tr; k < tile_ranges.size() && tile_ranges[k].lo < end; ++k) {
+            const uint64_t lo = std::max(tile_ranges[k].lo, s.first), hi = std::min(tile_ranges[k].hi, end);
+            if (hi > lo && hi - lo >= tile) needs_tile_table = true;
         }
         if (!needs_tile_table) continue;
         const uint32_t P = s.period;
@@ -297,25 +480,6 @@ void finalize(PlanResult &plan, uint32_t tile, bool use_rows)
     plan.lut_entries = pool;
     if (pool > 0xffffffffull) plan.error = "corrector tables exceed 2^32 entries";
     if ((plan.n_samples + tile - 1) / tile > 0xffffffffull) plan.error = "stream longer than 2^32 tiles";
-
-    // ---- everything no rows launch covers goes to tile-kernel launches
-    std::sort(covered.begin(), covered.end(), [](const Interval &a, const Interval &b) { return a.lo < b.lo; });
-    uint64_t pos = 0;
-    auto add_tiles = [&](uint64_t lo, uint64_t hi) {
-        if (lo >= hi) return;
-        Launch ln;
-        ln.kind = 1;
-        ln.tiles.m0 = lo;
-        ln.tiles.m1 = hi;
-        ln.tiles.tile_lo = lo / tile;
-        ln.tiles.n_tiles = (hi + tile - 1) / tile - ln.tiles.tile_lo;
-        plan.launches.push_back(ln);
-    };
-    for (const Interval &c : covered) {
-        add_tiles(pos, c.lo);
-        pos = std::max(pos, c.hi);
-    }
-    add_tiles(pos, plan.n_samples);
 
     // ---- one hint per 2^kHintShift samples: the stretch holding the first sample of that span
     const uint64_t n_hint = (plan.n_samples >> kHintShift) + 1;
@@ -356,6 +520,48 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
                     }
             for (uint64_t g = r.r0; g < r.A; ++g) generic(r.seg_lo, g);
             for (uint64_t g = r.B; g < r.r1; ++g) generic(r.seg_lo, g);
+        } else if (ln.kind == 2) {
+            const WalkArgs &wa = ln.walk;
+            for (uint32_t b = 0; b < wa.n_walk_wg; ++b) {
+                uint32_t wi = plan.walk_hint[b >> kWalkHintShift];
+                while (plan.walk[wi + 1].wg_base <= b) ++wi;
+                const WalkSeg &ws = plan.walk[wi];
+                const TableBuild *tb = nullptr;
+                for (const TableBuild &t : plan.tables) if (t.off == ws.tab_off) tb = &t;
+                const uint32_t q = b - ws.wg_base;
+                const uint32_t nw8 = (ws.nw + 7u) & ~7u;
+                const uint32_t chunk = (uint32_t)(((uint64_t)q * ws.div_m) >> ws.div_s);
+                const uint32_t w = q - chunk * nw8;
+                if (w >= ws.nw) continue;
+                const uint32_t rpw = wa.waves * wa.rows_per_wave;
+                const uint32_t r_lo = chunk * rpw;
+                const uint32_t r_hi = std::min<uint64_t>(ws.rows, (uint64_t)r_lo + rpw);
+                for (uint32_t r = r_lo; r < r_hi; ++r) {
+                    const uint64_t ideal = ws.A + (uint64_t)r * ws.L;
+                    const uint64_t row0 = ideal & ~31ull;
+                    const uint32_t delta = (uint32_t)ideal & 31u;
+                    const uint64_t nxt = (ideal + ws.L) & ~31ull;
+                    const uint32_t rowlen = (uint32_t)((nxt < ws.E ? nxt : ws.E) - row0);
+                    for (uint32_t cl = 0; cl < kWalkWindow; ++cl) {
+                        const uint32_t c = w * kWalkWindow + cl;
+                        if (c >= rowlen) break;                                   // lanes past the row store to the sink
+                        const uint32_t x = w * kWalkWindow + (kWalkPad - delta + cl);   // slice base + index in the slice
+                        if (kWalkPad - delta + cl >= kWalkSlice || x >= tb->n_entries) { put(row0 + c, 0xffffffffu); continue; }
+                        put(row0 + c, (uint32_t)(((uint64_t)(tb->n_first - 1u) + x) % tb->period) + 1u);
+                    }
+                }
+            }
+            for (uint32_t e = 0; e < wa.n_left_wg; ++e) {
+                uint32_t li = plan.left_hint[e >> kLeftHintShift];
+                while (plan.left[li + 1].wg_off <= e) ++li;
+                const LeftRange &lr = plan.left[li];
+                const DevSeg &sg = plan.segs[lr.seg];
+                const uint32_t o0 = (e - lr.wg_off) * kLeftBlock;
+                for (uint32_t o = 0; o < kLeftBlock && o0 + o < lr.len; ++o) {
+                    const uint64_t g = lr.start + o0 + o;
+                    put(g, counter_at(sg, g - sg.first));
+                }
+            }
         } else {
             const TileArgs &t = ln.tiles;
             for (uint64_t tile = t.tile_lo; tile < t.tile_lo + t.n_tiles; ++tile) {

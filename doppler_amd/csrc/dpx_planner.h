@@ -31,9 +31,18 @@ struct TableBuild {     // one corrector table to fill at plan time
 };
 
 struct Launch {
-    int kind;           // 0 = rows kernel, 1 = tile kernel
+    int kind;           // 0 = rows kernel, 1 = tile kernel, 2 = walk kernel
     RowsArgs rows;
     TileArgs tiles;
+    WalkArgs walk;
+};
+
+// finalize(): which kernels a plan may use
+enum KernelChoice {
+    kChooseAuto = 0,      // rows kernel for up to 8 long stretches, else the walk kernel, else tiles
+    kChooseTileOnly = 1,  // tile kernel only (measurement A/B)
+    kChooseWalk = 2,      // walk kernel wherever a stretch qualifies (measurement A/B)
+    kChooseRows = 3,      // rows kernel or tiles, never the walk kernel (measurement A/B)
 };
 
 struct PlanResult {
@@ -46,6 +55,11 @@ struct PlanResult {
     std::vector<uint32_t> hint;      // stretch index per 2^kHintShift samples
     std::vector<TableBuild> tables;
     std::vector<Launch> launches;
+    // walk-kernel launch (at most one per plan), each list closed by a sentinel
+    std::vector<WalkSeg> walk;
+    std::vector<uint32_t> walk_hint;  // WalkSeg index per 2^kWalkHintShift workgroups
+    std::vector<LeftRange> left;
+    std::vector<uint32_t> left_hint;  // LeftRange index per 2^kLeftHintShift leftover workgroups
     const char *error = nullptr;     // set by finalize() when the plan cannot be laid out
 };
 
@@ -54,8 +68,7 @@ void plan_append(PlanResult &plan, float ratio, uint64_t count, uint32_t &sample
 
 // after the last plan_append: choose the kernel for every stretch, lay out the
 // corrector tables, build the hint table and the launch list.
-// use_rows = false keeps everything on the tile kernel (measurement A/B).
-void finalize(PlanResult &plan, uint32_t tile, bool use_rows);
+void finalize(PlanResult &plan, uint32_t tile, int choice /* KernelChoice */);
 
 // Host mirror of the kernels' index arithmetic (no arithmetic on samples): for every
 // sample of a finalized plan, the counter value the launches would use, and how many

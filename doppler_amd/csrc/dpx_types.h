@@ -32,6 +32,7 @@ static_assert(sizeof(DevSeg) == 48, "DevSeg is read with scalar loads");
 
 constexpr uint32_t kSegRows = 2u;        // (most of) this stretch is served by a rows-kernel launch
 constexpr uint32_t kSegTileTable = 4u;   // lut_off / c0 / tmod describe a tile-kernel table
+constexpr uint32_t kSegWalk = 8u;        // (most of) this stretch is a matrix of the walk-kernel launch
 
 // the first 32 bytes, as exposed through the C ABI (dpx_stretch)
 struct StretchView {
@@ -74,6 +75,55 @@ struct RowsArgs {
     uint32_t P;          // period of the stretch (L is a multiple of it)
 };
 
+// ---- walk kernel: many tabulated periodic stretches in ONE launch (track mode: one stretch per second of stream).
+// A stretch [A, E) is viewed as rows of L samples (L a multiple of the period), row r starting at the 32-sample
+// boundary at or below A + r * L, so every wavefront access is a whole number of 128-byte lines whatever the
+// period.  A workgroup takes one 256-sample column window of eight consecutive rows (4 wavefronts x 2 rows): the
+// window's correctors are read once and shared through LDS (the tile kernel reads 8 bytes of table per sample,
+// cold, because all tiles of a one-second stretch are in flight at once).  Row r is shifted left by
+// delta_r = (A + r * L) mod 32 samples, so its lanes index the table at kWalkPad - delta_r + column.
+struct WalkSeg {
+    uint64_t A;            // first sample of the matrix (multiple of 32)
+    uint64_t E;            // one past its last sample (multiple of 32)
+    uint32_t L;            // row length in samples
+    uint32_t tab_off;      // table-pool entry index; entry x = corrector of column x - kWalkPad, 256 nw + kWalkPad entries
+    uint32_t wg_base;      // first workgroup of this stretch (multiple of 8)
+    uint32_t nw;           // column windows per row
+    uint32_t rows;
+    uint32_t n_chunks;     // row chunks: ceil(rows / (wavefronts x rows per wavefront))
+    uint32_t div_m, div_s; // (wg - wg_base) / nw8 == ((wg - wg_base) * div_m) >> div_s, nw8 = nw rounded up to 8
+};
+static_assert(sizeof(WalkSeg) == 48, "WalkSeg is read with scalar loads");
+
+// what the walk kernel's matrices do not cover (heads, tails, lead-ins, untabulated stretches too short for
+// a tile launch): ranges inside ONE stretch each, evaluated sample by sample in 256-sample blocks
+struct LeftRange {
+    uint64_t start;
+    uint32_t len;
+    uint32_t seg;          // index of the stretch holding the range
+    uint32_t wg_off;       // first block of this range among the leftover workgroups
+    uint32_t pad;
+};
+static_assert(sizeof(LeftRange) == 24, "LeftRange is read with scalar loads");
+
+constexpr uint32_t kWalkPad = 32;          // table entries before column 0 (the largest row shift is 31)
+constexpr uint32_t kWalkWindow = 256;      // samples per column window
+constexpr uint32_t kWalkMinL = 8192;       // shorter periods use a multiple as the row length
+constexpr int kWalkHintShift = 6;          // one WalkSeg hint per 64 workgroups
+constexpr int kLeftHintShift = 4;          // one LeftRange hint per 16 leftover workgroups
+constexpr uint32_t kLeftBlock = 1024;      // samples per leftover workgroup
+constexpr uint32_t kWalkWaves = 4;         // wavefronts per workgroup ...
+constexpr uint32_t kWalkRowsPerWave = 2;   // ... and rows per wavefront: 8 rows share one table slice
+constexpr uint32_t kWalkSlice = kWalkWindow + kWalkPad;   // table entries a window needs: 288
+constexpr uint32_t kWalkSinkBytes = 512 * 16;             // where lanes without a sample store
+
+struct WalkArgs {
+    uint32_t n_walk_wg;    // workgroups walking matrices
+    uint32_t n_left_wg;    // workgroups evaluating leftover ranges
+    uint32_t n_segs;
+    uint32_t waves, rows_per_wave;   // workgroup geometry the descriptors were laid out for
+};
+
 struct TileArgs {
     uint64_t tile_lo;    // first tile of this launch (global tiling from sample 0)
     uint64_t n_tiles;
@@ -86,6 +136,9 @@ int launch_tiles(const void *d_in, int in_fmt, void *d_out, int out_fmt, const D
                  bool fma, const LaunchGeom &g, void *stream);
 int launch_rows(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,
                 const void *d_lut, const RowsArgs &r, bool fma, void *stream);
+int launch_walk(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs, const void *d_lut,
+                const WalkSeg *d_walk, const uint32_t *d_walk_hint, const LeftRange *d_left,
+                const uint32_t *d_left_hint, void *d_sink, const WalkArgs &w, bool fma, void *stream);
 int launch_build_lut(void *d_lut_entries, uint32_t period, uint32_t n_first, uint32_t n_entries,
                      float ratio, bool fma, void *stream);
 int launch_copy(const void *d_in, void *d_out, uint64_t n_bytes, void *stream);

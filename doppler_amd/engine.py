@@ -263,6 +263,19 @@ def plan_simulate(segments, samplerate, samplenum=0, block=0, vecs=0, variant=3)
     return counters, writes
 
 
+def plan_layout(segments, samplerate, samplenum=0, block=0, vecs=0, variant=3):
+    """Host-only: how a plan is laid out over the kernels (dict of the dpx_layout fields). Needs no GPU."""
+    lib = _lib_handle()
+    segs = list(segments)
+    arr = (_lib.Segment * max(1, len(segs)))()
+    for i, (cnt, hz) in enumerate(segs):
+        arr[i].n_samples = int(cnt)
+        arr[i].shift_hz = float(hz)
+    lay = _lib.Layout()
+    check(lib.dpx_plan_layout(arr, len(segs), int(samplerate), int(samplenum), block, vecs, variant, C.byref(lay)))
+    return {name: getattr(lay, name) for name, _ in _lib.Layout._fields_}
+
+
 def find_reset(shift_hz, samplerate, n_start, max_scan):
     lib = _lib_handle()
     n = C.c_uint32()

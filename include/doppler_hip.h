@@ -140,6 +140,21 @@ int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
                       uint32_t samplenum0, int block, int vecs, int variant,
                       uint32_t *counters, uint8_t *writes, uint64_t n_samples);
 
+/* Host-only: how the planner lays a segment list out over the kernels (what dpx_run_device will launch). */
+typedef struct dpx_layout {
+    uint64_t n_samples;
+    uint64_t rows_samples;      /* produced by rows-kernel matrices */
+    uint64_t walk_samples;      /* produced by walk-kernel matrices */
+    uint64_t tile_samples;      /* inside tile-kernel launches */
+    uint64_t single_samples;    /* evaluated one by one (ragged edges of rows launches, leftover ranges) */
+    uint64_t table_entries;     /* (cos, sin) pairs tabulated at plan time */
+    uint32_t n_stretches;
+    uint32_t rows_launches, tile_launches, walk_launches;
+    uint32_t walk_matrices, walk_workgroups, leftover_ranges, leftover_workgroups;
+} dpx_layout;
+int dpx_plan_layout(const dpx_segment *segs, size_t n_segs, uint32_t samplerate, uint32_t samplenum0,
+                    int block, int vecs, int variant, dpx_layout *out);
+
 /* ------------------------------------------------ track mode, host side (N2)
  * Host-only.  The per-block shift schedule of `doppler track --time` (reference
  * src/main.rs:156-184: one-block lag, whole seconds truncated through f32, f32 offset add) for a
@@ -212,11 +227,13 @@ int dpx_debug_copy(dpx_ctx *ctx, const void *d_in, void *d_out, size_t n_bytes, 
 /* Measurement knobs (0 keeps the current value); they apply to plans created afterwards.
  * block / vecs: tile-kernel geometry, lanes per workgroup (128 or 256) and 4-sample groups
  *          per lane (1 or 2); the rows kernel always runs one wavefront x 2 rows.
- * variant: 3 = auto: tabulated correctors when the period is <= 8192 samples (rows kernel for
- *              stretches of >= 65536 samples, tile kernel otherwise), sincos per sample else;
+ * variant: 3 = auto: correctors tabulated wherever a period repeats at least twice; rows kernel for up to
+ *              eight long stretches (const mode), walk kernel for more (track mode), tile kernel for the rest;
  *          1 = sincos per sample wherever the period allows it (>= 4);
  *          2 = tabulate whenever the period fits;
- *          4 = auto, but keep everything on the tile kernel. */
+ *          4 = auto, but keep everything on the tile kernel;
+ *          5 = auto, but use the walk kernel wherever a stretch qualifies;
+ *          6 = auto, but never the walk kernel. */
 int dpx_set_tuning(dpx_ctx *ctx, int block, int vecs, int variant);
 
 /* Which build of glibc's sincosf the correctors reproduce bit-for-bit:

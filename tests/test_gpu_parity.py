@@ -293,6 +293,52 @@ def test_track_segments_bulk_vs_oracle(ctx, orc):
         assert_same_bytes(got, want, outtype, "track %s->%s" % (intype, outtype))
 
 
+def oracle_segments(orc, x, intype, outtype, segs, rate, sn0=0):
+    cx = orc.convert_iqi16_to_complex(x) if intype == "i16" else orc.convert_iqf32_to_complex(x)
+    outs, sn, pos = [], sn0, 0
+    for cnt, hz in segs:
+        o, sn = orc.shift_frequency(cx[pos:pos + cnt], sn, hz, rate)
+        outs.append(o)
+        pos += cnt
+    o = np.concatenate(outs)
+    return (orc.pack_i16(o) if outtype == "i16" else orc.pack_f32(o)), sn
+
+
+@pytest.mark.parametrize("intype,outtype", [("i16", "i16"), ("f32", "f32"), ("i16", "f32"), ("f32", "i16")])
+def test_walk_kernel_plans_vs_oracle(ctx, orc, intype, outtype):
+    """Track-shaped plans with more than eight tabulated stretches run as ONE walk-kernel launch (matrices with
+    shifted, line-aligned rows; leftover blocks for heads, tails and lead-ins) plus tile launches for long
+    untabulated gaps — byte for byte against the oracle, odd periods, short periods, carried counters."""
+    import doppler_amd
+    rng = np.random.default_rng(77)
+    plans = [
+        ([(120000 + 2048 * int(rng.integers(0, 9)), float(np.float32(rng.uniform(-9000, 9000)))) for _ in range(12)], 256000, 0),
+        ([(30000, 1000.0 * (2 * k + 1)) for k in range(10)], 1024000, 0),
+        ([(50000 + 17 * k, 333.0 + k) for k in range(10)], 48000, 5),
+    ]
+    for i, (segs, rate, sn0) in enumerate(plans):
+        lay = doppler_amd.plan_layout(segs, rate, sn0)
+        assert lay["walk_launches"] == 1 and lay["walk_matrices"] >= 8, lay
+        n = sum(c for c, _ in segs)
+        x = make_iq(intype, n, 900 + i, full_scale=True)
+        want, sn = oracle_segments(orc, x, intype, outtype, segs, rate, sn0)
+        got, fin = run_bulk(ctx, x, intype, outtype, segs, rate, sn0=sn0)
+        assert fin == sn
+        assert_same_bytes(got, want, outtype, "walk plan %d %s->%s" % (i, intype, outtype))
+    # the same arithmetic when a single long stretch is forced onto the walk kernel (row chunks of 32 rows)
+    segs, rate = [(3000000 + 77, 5001.0)], 1024000
+    x = make_iq(intype, segs[0][0], 950)
+    want, sn = oracle_segments(orc, x, intype, outtype, segs, rate)
+    ctx.set_tuning(0, 0, 5)
+    try:
+        assert doppler_amd.plan_layout(segs, rate, variant=5)["walk_matrices"] == 1
+        got, fin = run_bulk(ctx, x, intype, outtype, segs, rate)
+    finally:
+        ctx.set_tuning(0, 0, 3)
+    assert fin == sn
+    assert_same_bytes(got, want, outtype, "forced walk %s->%s" % (intype, outtype))
+
+
 def test_chunked_equals_whole(ctx, orc):
     """Time-chunk sharding: 5 block-aligned chunks seeded from the closed form reproduce
     the single-pass output byte for byte."""

@@ -78,6 +78,11 @@ def test_find_reset_and_period(orc):
     assert engine.find_reset(3.0, 1024000, 1, 2000000) == 1024000
 
 
+def writes_ok(w, segs, rate, sn0, block, vecs, variant):
+    """Every sample produced exactly once."""
+    return bool((w == 1).all())
+
+
 def test_launch_lists_cover_every_sample_once(orc):
     """dpx_plan_simulate mirrors the kernels' index arithmetic on the host: every sample written exactly
     once and with the counter value of the sequential rule — for the rows kernel, the tile kernel, the
@@ -91,11 +96,37 @@ def test_launch_lists_cover_every_sample_once(orc):
     ]
     for segs, rate, sn0 in cases:
         want, _ = oracle_counters(orc, segs, rate, sn0)
-        for variant in (3, 4, 1, 2):
+        for variant in (3, 4, 1, 2, 5, 6):
             for block, vecs in ((256, 1), (128, 2)):
                 c, w = doppler_amd.plan_simulate(segs, rate, sn0, block, vecs, variant)
-                assert (w == 1).all(), (segs, variant, block, vecs, np.flatnonzero(w != 1)[:5])
+                assert writes_ok(w, segs, rate, sn0, block, vecs, variant), (segs, variant, block, vecs, np.flatnonzero(w != 1)[:5])
                 assert np.array_equal(c, want), (segs, variant, block, vecs, np.flatnonzero(c != want)[:5])
+
+
+def test_walk_kernel_plans(orc):
+    """Track-shaped plans (many constant-shift segments, counters carried across): more than eight tabulated
+    stretches sends the plan to the walk kernel (one launch: matrices with 32-sample-aligned shifted rows, leftover
+    blocks, tile launches for long uncovered gaps).  Index arithmetic checked against the sequential rule."""
+    rng = np.random.default_rng(77)
+    plans = [
+        # twelve segments of arbitrary f32 shifts: odd periods, lead-ins where the carried counter exceeds the new period
+        ([(120000 + 2048 * int(rng.integers(0, 9)), float(np.float32(rng.uniform(-9000, 9000)))) for _ in range(12)], 256000, 0),
+        # short periods (row length is a multiple of the period), power-of-two and odd
+        ([(30000, 1000.0 * (2 * k + 1)) for k in range(10)], 1024000, 0),
+        ([(50000 + 17 * k, 333.0 + k) for k in range(10)], 48000, 5),
+        # a long untabulated stretch in the middle becomes a tile launch; a short one a leftover range
+        ([(30000, 500.0 + k) for k in range(9)] + [(90000, 0.001)] + [(3000, 0.002)] + [(30000, 700.0 + k) for k in range(3)], 64000, 0),
+    ]
+    for i, (segs, rate, sn0) in enumerate(plans):
+        want, _ = oracle_counters(orc, segs, rate, sn0)
+        lay = doppler_amd.plan_layout(segs, rate, sn0, 128, 2, 3)
+        assert sum(lay[k] for k in ("rows_samples", "walk_samples", "tile_samples", "single_samples")) == lay["n_samples"]
+        if i < 3:    # these really are walk-kernel plans: matrices, leftover ranges, and (first plan) tile launches
+            assert lay["walk_launches"] == 1 and lay["walk_matrices"] >= 8 and lay["leftover_ranges"] > 0, lay
+        for variant in (3, 5):
+            c, w = doppler_amd.plan_simulate(segs, rate, sn0, 128, 2, variant)
+            assert (w == 1).all(), (segs[:3], variant, np.flatnonzero(w != 1)[:5], w[np.flatnonzero(w != 1)[:5]])
+            assert np.array_equal(c, want), (segs[:3], variant, np.flatnonzero(c != want)[:5])
 
 
 def test_chunk_sharding_seeds(orc):
@@ -161,9 +192,9 @@ def test_random_plans_against_sequential_rule(orc):
             segs.append((int(rng.integers(1, 9000)) if rng.random() < 0.7 else int(rng.integers(60000, 90000)), hz))
         sn0 = int(rng.choice([0, 1, 2, 1000, 65535, 1 << 20]))
         want, sn_end = oracle_counters(orc, segs, rate, sn0)
-        variant = int(rng.choice([3, 4, 1, 2]))
+        variant = int(rng.choice([3, 4, 1, 2, 5, 5, 6]))
         block, vecs = [(256, 1), (128, 2), (128, 1), (256, 2)][case % 4]
         c, w = doppler_amd.plan_simulate(segs, rate, sn0, block, vecs, variant)
-        assert (w == 1).all(), (case, segs, rate, sn0, variant)
+        assert writes_ok(w, segs, rate, sn0, block, vecs, variant), (case, segs, rate, sn0, variant)
         assert np.array_equal(c, want), (case, segs, rate, sn0, variant, int(np.flatnonzero(c != want)[0]))
         assert doppler_amd.plan_describe(segs, rate, sn0)[1] == sn_end
