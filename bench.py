@@ -113,8 +113,11 @@ def run_track(args, world, rank, dev, ctx):
     lo, hi = shard.chunk_bounds(total, world, rank, bytes_per_sample=bi)
     before, inside = shard.segments_for_chunk(segs, lo, hi)
     t0 = time.perf_counter()
-    plan = ctx.plan_segments(inside, rate, samplenum=shard.seed_for_segments(before, rate))
+    seed = shard.seed_for_segments(before, rate)
+    plan = ctx.plan_segments(inside, rate, samplenum=seed)
     plan_ms = (time.perf_counter() - t0) * 1e3
+    import doppler_amd
+    layout = doppler_amd.plan_layout(inside, rate, seed)
     n = hi - lo
     x = (torch.randint(-23170, 23171, (2 * n,), dtype=torch.int16, device=dev) if it == "i16"
          else torch.rand(2 * n, dtype=torch.float32, device=dev) * 2 - 1)
@@ -153,7 +156,8 @@ def run_track(args, world, rank, dev, ctx):
             "config": {"workload": name, "samples_total": total, "samples_per_gpu": n, "segments_total": len(segs),
                        "segments_this_rank": len(inside), "plan_ms": round(plan_ms, 2), "in": it, "out": ot},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "dpx::tile_kernel",
+                         "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "kernel": "dpx::walk_kernel" if layout["walk_launches"] else "dpx::tile_kernel", "layout": layout,
                          "avg_launch_ms": round(kms, 4), "algorithmic_bytes_per_launch": n * (bi + bo)},
         }), flush=True)
     plan.close()

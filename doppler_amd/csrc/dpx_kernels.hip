@@ -35,28 +35,46 @@ __device__ __forceinline__ void unpack_i16(uint32_t w, float &re, float &im)
     im = (float)(int16_t)(w >> 16) * 0x1p-15f;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // dsp.rs:123 with num-complex 0.1.35 Mul: (a*c - b*s, a*s + b*c); every product and
 // the sum/difference individually rounded (Rust never contracts to fma).
-__device__ __forceinline__ void mix(float a, float b, float c, float s, float &re, float &im)
+// Three packed instructions on the register pairs (a, b) and (c, s) as they come out of the loads:
+//   t0 = (a*c, a*s)     t1 = (b*s, b*c)     result = (t0.lo - t1.lo, t0.hi + t1.hi)
+// op_sel / op_sel_hi pick the half of each source pair that feeds the low / high result lane; neg_lo
+// negates the low-lane input of the second operand, so a*c + (-(b*s)) is the IEEE subtraction itself.
+__device__ __forceinline__ f32x2 mix2(f32x2 ab, f32x2 cs)
 {
-    re = __fsub_rn(__fmul_rn(a, c), __fmul_rn(b, s));
-    im = __fadd_rn(__fmul_rn(a, s), __fmul_rn(b, c));
+    f32x2 t0, t1, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t0) : "v"(ab), "v"(cs));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t1) : "v"(ab), "v"(cs));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(t0), "v"(t1));
+    return r;
 }
 
-// Rust `f32 as i16`: truncate toward zero, saturate, NaN -> 0.
-__device__ __forceinline__ int f32_as_i16(float x)
+__device__ __forceinline__ void mix(float a, float b, float c, float s, float &re, float &im)
 {
-    x = (x != x) ? 0.0f : x;
-    x = fminf(fmaxf(x, -32768.0f), 32767.0f);
-    return (int)x;
+    const f32x2 r = mix2(f32x2{a, b}, f32x2{c, s});
+    re = r.x;
+    im = r.y;
+}
+
+// Rust `f32 as i16`: truncate toward zero, saturate, NaN -> 0.  v_cvt_i32_f32 truncates, saturates to the
+// i32 range and turns NaN into 0; v_cvt_pk_i16_i32 then saturates both values to i16 and packs them.
+__device__ __forceinline__ int f32_as_i32_sat(float x)
+{
+    int i;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(i) : "v"(x));
+    return i;
 }
 
 // main.rs:77-83: i = (re * 32767.0) as i16, little-endian I then Q.
 __device__ __forceinline__ uint32_t pack_i16(float re, float im)
 {
-    const int i = f32_as_i16(__fmul_rn(re, 32767.0f));
-    const int q = f32_as_i16(__fmul_rn(im, 32767.0f));
-    return ((uint32_t)i & 0xffffu) | ((uint32_t)q << 16);
+    const f32x2 sc = f32x2{re, im} * 32767.0f;           // one v_pk_mul_f32, each product rounded on its own
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const s16x2 p = __builtin_amdgcn_cvt_pk_i16(f32_as_i32_sat(sc.x), f32_as_i32_sat(sc.y));
+    return __builtin_bit_cast(uint32_t, p);
 }
 
 template <int FMT> struct Fmt;
