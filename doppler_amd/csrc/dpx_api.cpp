@@ -516,9 +516,12 @@ int dpx_plan_layout(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
         }
     }
     if (!plan.walk.empty()) {
-        out->walk_matrices = (uint32_t)plan.walk.size() - 1;
         out->leftover_ranges = (uint32_t)plan.left.size() - 1;
-        for (size_t i = 0; i + 1 < plan.walk.size(); ++i) out->walk_samples += plan.walk[i].E - plan.walk[i].A;
+        for (size_t i = 0; i + 1 < plan.walk.size(); ++i) {
+            if (plan.walk[i].row0 != 0) continue;                 // one descriptor per row chunk: count matrices once
+            ++out->walk_matrices;
+            out->walk_samples += plan.walk[i].E - plan.walk[i].A;
+        }
         for (size_t i = 0; i + 1 < plan.left.size(); ++i) out->single_samples += plan.left[i].len;
     }
     return DPX_OK;

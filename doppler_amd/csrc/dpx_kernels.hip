@@ -419,14 +419,8 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
         uint32_t wi = whint[b >> kWalkHintShift];
         while (wsegs[wi + 1].wg_base <= b) ++wi;                  // the list ends with a sentinel
         const WalkSeg ws = wsegs[wi];
-        // workgroups of a stretch: row chunk major, window fastest (a chunk sweeps its rows contiguously), the window
-        // count padded to a multiple of 8: workgroup ids that differ by a multiple of 8 run on the same XCD, so all
-        // the chunks of one window find its table slice in that XCD's L2
-        const uint32_t q = b - ws.wg_base;
-        const uint32_t nw8 = (ws.nw + 7u) & ~7u;
-        const uint32_t chunk = (uint32_t)(((uint64_t)q * ws.div_m) >> ws.div_s);   // q / nw8
-        const uint32_t w = q - chunk * nw8;
-        if (w >= ws.nw) return;                                   // padding
+        const uint32_t w = b - ws.wg_base;
+        if (w >= ws.nw) return;                                   // chunks are padded to a multiple of 8 workgroups
 
         // this window's slice of the table: entry j = corrector of column 256 w + j - kWalkPad
         const float2 *tab = lut_pool + ws.tab_off + w * kWalkWindow;
@@ -441,7 +435,7 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
             }
         }
 
-        const uint32_t r0 = chunk * (WAVES * U) + wave * U;
+        const uint32_t r0 = ws.row0 + wave * U;
         qvec qin[U][NV];
         uint32_t li[U][NV];                                       // index into the slice
         uint8_t *op[U][NV];
@@ -531,8 +525,14 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
             const uint32_t o = k * THREADS + tid;
             if (o0 + o >= lr.len) break;
             uint32_t n;
-            if (P != 0) n = (uint32_t)(((uint64_t)base + o) % P) + 1u;
-            else        n = base + o;
+            if (P == 0) {
+                n = base + o;
+            } else if (P >= kLeftBlock) {                         // base < P and o < kLeftBlock: at most one wrap
+                const uint64_t t = (uint64_t)base + o;
+                n = (uint32_t)(t >= P ? t - P : t) + 1u;
+            } else {
+                n = (uint32_t)(((uint64_t)base + o) % P) + 1u;
+            }
             float c, s, a, bq, re, im;
             corrector<FMA>(sg.ratio, n, c, s);
             load_one<IN_FMT>(in, g0 + o, a, bq);

@@ -178,7 +178,7 @@ uint32_t pick_rows_per_wave(uint32_t P)
 
 struct Interval { uint64_t lo, hi; };
 
-constexpr uint64_t kWalkTileMin = 1u << 16;      // an uncovered gap at least this long gets its own tile launch ...
+static const uint64_t kWalkTileMin = [] { const char *e = getenv("DPX_WALK_TILEMIN"); return e ? strtoull(e, nullptr, 0) : (1ull << 22); }();      // an uncovered gap at least this long gets its own tile launch ...
 constexpr size_t kWalkMaxTileLaunches = 8;       // ... up to this many; the rest is evaluated by leftover workgroups
 
 struct WalkShape { uint32_t waves, rows_per_wave; };
@@ -198,7 +198,6 @@ WalkShape walk_shape()
 // matrix of the walk kernel for one stretch (dpx_types.h, WalkSeg); false if the stretch does not qualify
 bool walk_geometry(const DevSeg &s, WalkSeg *w)
 {
-    const WalkShape shape = walk_shape();
     if (s.lut_len == 0 || s.period == 0) return false;
     const uint64_t end = s.first + s.count;
     const uint64_t A = (s.first + 31) & ~31ull, E = end & ~31ull;
@@ -217,23 +216,26 @@ bool walk_geometry(const DevSeg &s, WalkSeg *w)
     w->wg_base = 0;
     w->nw = (uint32_t)nw;
     w->rows = (uint32_t)rows;
-    const uint64_t rpw = shape.waves * shape.rows_per_wave;
-    const uint64_t n_chunks = (rows + rpw - 1) / rpw;
-    if (n_chunks > 0x0fffffffull) return false;
-    w->n_chunks = (uint32_t)n_chunks;
-    // exact q / d for q < 2^31, d = nw padded to a multiple of 8: M = ceil(2^(31+s) / d), s = ceil(log2 d)
-    const uint64_t d = (nw + 7) & ~7ull;
-    uint32_t sh = 0;
-    while ((1ull << sh) < d) ++sh;
-    w->div_s = 31 + sh;
-    w->div_m = (uint32_t)(((1ull << w->div_s) + d - 1) / d);
+    w->row0 = 0;
+    w->pad[0] = w->pad[1] = 0;
     return true;
+}
+
+uint32_t walk_chunks(const WalkSeg &w)
+{
+    const uint32_t rpw = walk_shape().waves * walk_shape().rows_per_wave;
+    return (uint32_t)(((uint64_t)w.rows + rpw - 1) / rpw);
 }
 
 uint64_t walk_workgroups(const WalkSeg &w)
 {
-    return (uint64_t)((w.nw + 7) / 8) * 8 * w.n_chunks;     // groups of 8 windows x n_chunks, the last group padded
+    return (uint64_t)((w.nw + 7) & ~7u) * walk_chunks(w);     // every chunk padded to a multiple of 8 workgroups
 }
+
+// stretches whose chunks are interleaved in dispatch order.  Measured (profiles/r01_secondary_workloads.md): interleaving
+// 8 stretches so that a stretch's next chunk starts ~4 us after the previous one does NOT make the table slices hit in
+// the L2 (FETCH_SIZE unchanged) and costs 10 % on short-period plans (less contiguous sweeps), so: 1.
+constexpr size_t kWalkGroup = 1;
 
 }  // namespace
 
@@ -350,7 +352,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
     struct Piece { uint64_t lo, hi; uint32_t seg; };
     std::vector<Piece> pieces;
     if (use_walk) {
-        uint64_t wg = 0;
+        std::vector<WalkSeg> mats;                   // one per qualifying stretch, in stream order
         for (size_t i = 0; i < ns; ++i) {
             DevSeg &s = plan.segs[i];
             const uint64_t end = s.first + s.count;
@@ -360,9 +362,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
                 continue;
             }
             s.flags |= kSegWalk;
-            w.wg_base = (uint32_t)wg;
             w.tab_off = (uint32_t)pool;
-            wg += walk_workgroups(w);
             // entry x = corrector of column x - kWalkPad, column 0 = sample A
             const uint32_t P = s.period;
             const uint32_t phase_a = counter_at(s, w.A - s.first) - 1u;
@@ -370,10 +370,28 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
             const uint32_t n_entries = w.nw * kWalkWindow + kWalkPad;     // every window reads a whole 288-entry slice
             plan.tables.push_back({pool, P, n_first, n_entries, s.ratio});
             pool += ((uint64_t)n_entries + 3) & ~3ull;
-            plan.walk.push_back(w);
+            mats.push_back(w);
             if (s.first < w.A) pieces.push_back({s.first, w.A, (uint32_t)i});
             if (w.E < end) pieces.push_back({w.E, end, (uint32_t)i});
             covered.push_back({w.A, w.E});
+        }
+        // dispatch order: stretch by stretch, chunk by chunk, window fastest (a chunk sweeps its eight rows contiguously);
+        // every chunk is padded to a multiple of 8 workgroups so that window w of every chunk runs on XCD w % 8
+        uint64_t wg = 0;
+        const uint32_t rpw = walk_shape().waves * walk_shape().rows_per_wave;
+        for (size_t g0 = 0; g0 < mats.size(); g0 += kWalkGroup) {
+            const size_t g1 = std::min(mats.size(), g0 + kWalkGroup);
+            uint32_t max_chunks = 0;
+            for (size_t m = g0; m < g1; ++m) max_chunks = std::max(max_chunks, walk_chunks(mats[m]));
+            for (uint32_t c = 0; c < max_chunks; ++c)
+                for (size_t m = g0; m < g1; ++m) {
+                    if (c >= walk_chunks(mats[m])) continue;
+                    WalkSeg w = mats[m];
+                    w.row0 = c * rpw;
+                    w.wg_base = (uint32_t)wg;
+                    wg += (w.nw + 7) & ~7u;
+                    plan.walk.push_back(w);
+                }
         }
         // uncovered pieces that touch form a gap; long gaps become tile launches, the rest leftover ranges
         std::vector<Interval> gaps_for_tiles;
@@ -528,14 +546,10 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
                 const WalkSeg &ws = plan.walk[wi];
                 const TableBuild *tb = nullptr;
                 for (const TableBuild &t : plan.tables) if (t.off == ws.tab_off) tb = &t;
-                const uint32_t q = b - ws.wg_base;
-                const uint32_t nw8 = (ws.nw + 7u) & ~7u;
-                const uint32_t chunk = (uint32_t)(((uint64_t)q * ws.div_m) >> ws.div_s);
-                const uint32_t w = q - chunk * nw8;
+                const uint32_t w = b - ws.wg_base;
                 if (w >= ws.nw) continue;
-                const uint32_t rpw = wa.waves * wa.rows_per_wave;
-                const uint32_t r_lo = chunk * rpw;
-                const uint32_t r_hi = std::min<uint64_t>(ws.rows, (uint64_t)r_lo + rpw);
+                const uint32_t r_lo = ws.row0;
+                const uint32_t r_hi = (uint32_t)std::min<uint64_t>(ws.rows, (uint64_t)r_lo + wa.waves * wa.rows_per_wave);
                 for (uint32_t r = r_lo; r < r_hi; ++r) {
                     const uint64_t ideal = ws.A + (uint64_t)r * ws.L;
                     const uint64_t row0 = ideal & ~31ull;

@@ -82,16 +82,17 @@ struct RowsArgs {
 // window's correctors are read once and shared through LDS (the tile kernel reads 8 bytes of table per sample,
 // cold, because all tiles of a one-second stretch are in flight at once).  Row r is shifted left by
 // delta_r = (A + r * L) mod 32 samples, so its lanes index the table at kWalkPad - delta_r + column.
-struct WalkSeg {
+// The launch is a list of row chunks (WalkSeg), stretch by stretch, each chunk padded to a multiple of 8 workgroups.
+struct WalkSeg {           // one row chunk (kWalkWaves x kWalkRowsPerWave rows) of one stretch's matrix
     uint64_t A;            // first sample of the matrix (multiple of 32)
     uint64_t E;            // one past its last sample (multiple of 32)
     uint32_t L;            // row length in samples
     uint32_t tab_off;      // table-pool entry index; entry x = corrector of column x - kWalkPad, 256 nw + kWalkPad entries
-    uint32_t wg_base;      // first workgroup of this stretch (multiple of 8)
+    uint32_t wg_base;      // first workgroup of this chunk (multiple of 8); workgroup wg_base + w takes window w
     uint32_t nw;           // column windows per row
-    uint32_t rows;
-    uint32_t n_chunks;     // row chunks: ceil(rows / (wavefronts x rows per wavefront))
-    uint32_t div_m, div_s; // (wg - wg_base) / nw8 == ((wg - wg_base) * div_m) >> div_s, nw8 = nw rounded up to 8
+    uint32_t rows;         // rows of the matrix
+    uint32_t row0;         // first row of this chunk
+    uint32_t pad[2];
 };
 static_assert(sizeof(WalkSeg) == 48, "WalkSeg is read with scalar loads");
 

@@ -1,1 +1,2 @@
-for shape in 4,2 2,2; do echo "== shape $shape"; DPX_WALK_SHAPE=$shape python tools/track_probe.py 2>&1 | grep auto | grep -v "4096\|16384\|same"; done
+python bench.py --workload track --steps 30 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['achieved'], d['roofline']['avg_launch_ms'], d['roofline']['layout'])"
+python tools/track_probe.py 2>&1 | grep "auto"
