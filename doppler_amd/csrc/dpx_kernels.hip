@@ -392,6 +392,15 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
 // no divergent branch: the compiler serialises loads that sit in divergent blocks, so a lane without a sample
 // (past the end of its row, or a row past the end of the matrix) loads from the start of the matrix instead and
 // stores to a scratch area (`sink`).
+// Walk kernel, f32 -> i16: loads are 16 bytes per lane (2 samples), which would make the stores 8 bytes per lane — and
+// 8-byte stores run at 2.4 TB/s in this kernel (measured; 16-byte stores with two 16-byte loads per lane at a 32-byte
+// lane stride: 5.0 TB/s).  So the packed results of a row go through a wavefront-private kilobyte of LDS and leave as
+// one 16-byte store per lane: both sides fully coalesced.
+template <int IN_FMT, int OUT_FMT> struct WalkVec {
+    static constexpr int S = RowVec<IN_FMT, OUT_FMT>::S;
+    static constexpr bool kTranspose = IN_FMT == DPX_FMT_F32 && OUT_FMT == DPX_FMT_I16;
+};
+
 template <int IN_FMT, int OUT_FMT, bool FMA, int WAVES, int U>
 __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restrict__ in,
                                                             uint8_t *__restrict__ out,
@@ -405,13 +414,15 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
                                                             const uint32_t *__restrict__ lhint,
                                                             const DevSeg *__restrict__ segs)
 {
-    constexpr int S = RowVec<IN_FMT, OUT_FMT>::S;                 // samples per lane per vector: 4 or 2
+    constexpr int S = WalkVec<IN_FMT, OUT_FMT>::S;                // samples per lane per vector: 4 or 2
     constexpr int NV = (int)kWalkWindow / (kRowsLanes * S);       // vectors per lane per row: 1 or 2
     constexpr int THREADS = WAVES * 64;
     constexpr int IB = Fmt<IN_FMT>::kBytes, OB = Fmt<OUT_FMT>::kBytes;
     constexpr int QW = S * IB / 4;                                // input dwords per vector
     typedef uint32_t qvec __attribute__((ext_vector_type(QW)));
+    constexpr bool XP = WalkVec<IN_FMT, OUT_FMT>::kTranspose;
     __shared__ float2 slice[kWalkSlice];
+    __shared__ uint32_t xpose[XP ? WAVES * U * (int)kWalkWindow : 1];   // packed i16 samples of one row per (wavefront, u)
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
 
     if (b < n_walk_wg) {
@@ -439,6 +450,7 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
         qvec qin[U][NV];
         uint32_t li[U][NV];                                       // index into the slice
         uint8_t *op[U][NV];
+        uint8_t *opx[U];                                          // f32 -> i16: where this lane's 4 consecutive samples go
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool valid = r0 + u < ws.rows;
@@ -457,6 +469,8 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
                 li[u][v] = kWalkPad - delta + cl;
                 op[u][v] = active ? out + g * OB : sink + tid * 16;
             }
+            const uint32_t c4 = w * kWalkWindow + lane * 4;
+            opx[u] = c4 < rowlen ? out + (row0 + c4) * OB : sink + tid * 16;
         }
 
 #pragma unroll
@@ -489,6 +503,12 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
                                    pack_i16(re[3], im[3])};
                         asm volatile("" : "+v"(o));   // keeps the vectoriser from rebuilding the store without its nt flag
                         __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(op[u][v]));
+                    } else if constexpr (XP) {
+                        u32x2 o;
+                        o[0] = pack_i16(re[0], im[0]);
+                        o[1] = pack_i16(re[1], im[1]);
+                        uint32_t *xp = xpose + (wave * U + u) * kWalkWindow + (uint32_t)v * (kRowsLanes * S) + lane * S;
+                        *reinterpret_cast<u32x2 *>(xp) = o;
                     } else {
                         u32x2 o;
                         o[0] = pack_i16(re[0], im[0]);
@@ -504,6 +524,13 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
                         __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(op[u][v]) + i);
                     }
                 }
+            }
+            if constexpr (XP) {
+                // the row's 256 packed samples are in LDS (same wavefront: LDS operations execute in order)
+                __builtin_amdgcn_wave_barrier();
+                u32x4 o = *reinterpret_cast<const u32x4 *>(xpose + (wave * U + u) * kWalkWindow + lane * 4);
+                asm volatile("" : "+v"(o));
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(opx[u]));
             }
         }
     } else {
