@@ -1,6 +1,8 @@
+"""Print the walk/tile kernel rows of the rocprofv3 databases written by tools/profile_track.sh <tag>."""
 import sqlite3, sys, glob
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 for sub in ("trace","pmc_fetch","pmc_write","pmc_l2"):
-    for db in glob.glob("gpurun_out/prof_track_r01c/%s/*.db" % sub):
+    for db in glob.glob("gpurun_out/prof_track_%s/%s/*.db" % (tag, sub)):
         c = sqlite3.connect(db)
         if sub == "trace":
             for r in c.execute("select name, count(*), avg(duration)/1e3, min(duration)/1e3 from kernels group by name order by sum(duration) desc limit 6"): print(sub, r[0][:60], r[1:])
