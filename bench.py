@@ -163,6 +163,54 @@ def run_track(args, world, rank, dev, ctx):
     plan.close()
 
 
+GATHER_TIMEOUT_S = 240
+
+
+def build_result(args, world, n, elapsed, avg_kernel_ms, gather):
+    """The one JSON line of the headline workload (rank 0)."""
+    achieved = n * BYTES_PER_SAMPLE / (avg_kernel_ms * 1e-3) / 1e9
+    traffic = None
+    traffic_src = None
+    prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(prof):
+        with open(prof) as f:
+            pj = json.load(f)
+        traffic = pj.get("hbm_bytes_per_launch")
+        traffic_src = "profiles/r01_pmc_traffic.json"
+    value = world * n * args.steps / elapsed / 1e6
+    result = {
+        "metric": "Msamples/s IQ throughput + % HBM roofline, 1 GB i16 stream, 1/2/4/8 GPUs",
+        "value": round(value, 1),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "doppler const -s 1024000 -i i16 --shift 5000, 1 GiB (268435456 samples) synthetic i16 IQ "
+                        "per GPU, device-resident in and out, i16 out (BASELINE.json configs[1])",
+            "samples_per_gpu": n, "in": "i16", "out": "i16", "shift_hz": SHIFT, "samplerate": RATE,
+            "sharding": "independent time-chunk per rank, counter seeded from the closed form; no data-path collective",
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "kernel": "dpx::rows_kernel<i16,i16>", "avg_launch_ms": round(avg_kernel_ms, 4),
+            "algorithmic_bytes_per_launch": n * BYTES_PER_SAMPLE,
+            "timing": "one HIP event pair on the launch stream around the K timed launches / K (includes the ~1.5 us inter-launch gap)",
+            "traffic_source": traffic_src,
+        },
+    }
+    if gather:
+        result["gather"] = gather
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,57 +295,43 @@ def main():
     # ---- outside the timed region: ordered gather (multi-GPU), host round trip, CPU baseline
     gather = None
     if world > 1:
-        barrier()
-        tg = time.perf_counter()
-        buf = shard.ordered_gather(out, [2 * n] * world, dst=0)
-        barrier()
-        tg = time.perf_counter() - tg
-        gather = {"what": "RCCL send/recv of every rank's output chunk into rank 0, in rank order (not in `value`)",
-                  "ms": round(tg * 1e3, 3), "GB_per_s_into_rank0": round((world - 1) * 4 * n / tg / 1e9, 2)}
-        del buf
+        # The gather is reported beside `value`, never inside it.  A watchdog keeps a stuck transfer from
+        # swallowing the measurement: after GATHER_TIMEOUT_S every rank gives up and rank 0 prints its line without it.
+        import threading
+        gather_state = {"done": False}
+
+        def give_up():
+            if gather_state["done"]:
+                return
+            if rank == 0:
+                line = result_line(None)
+                line["gather"] = {"error": "ordered gather did not finish within %d s; skipped" % GATHER_TIMEOUT_S}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        def result_line(g):
+            return build_result(args, world, n, elapsed, avg_kernel_ms, g)
+
+        timer = threading.Timer(GATHER_TIMEOUT_S, give_up)
+        timer.daemon = True
+        timer.start()
+        try:
+            barrier()
+            tg = time.perf_counter()
+            buf = shard.ordered_gather(out, [2 * n] * world, dst=0)
+            barrier()
+            tg = time.perf_counter() - tg
+            gather = {"what": "RCCL send/recv of every rank's output chunk into rank 0, in rank order (not in `value`)",
+                      "ms": round(tg * 1e3, 3), "GB_per_s_into_rank0": round((world - 1) * 4 * n / tg / 1e9, 2)}
+            del buf
+        except Exception as e:   # reported, not fatal: the headline does not depend on the gather
+            gather = {"error": str(e)[:300]}
+        gather_state["done"] = True
+        timer.cancel()
 
     result = None
     if rank == 0:
-        achieved = n * BYTES_PER_SAMPLE / (avg_kernel_ms * 1e-3) / 1e9
-        traffic = None
-        traffic_src = None
-        prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(prof):
-            with open(prof) as f:
-                pj = json.load(f)
-            traffic = pj.get("hbm_bytes_per_launch")
-            traffic_src = "profiles/r01_pmc_traffic.json"
-        value = world * n * args.steps / elapsed / 1e6
-        result = {
-            "metric": "Msamples/s IQ throughput + % HBM roofline, 1 GB i16 stream, 1/2/4/8 GPUs",
-            "value": round(value, 1),
-            "unit": "Msamples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": "doppler const -s 1024000 -i i16 --shift 5000, 1 GiB (268435456 samples) synthetic i16 IQ "
-                            "per GPU, device-resident in and out, i16 out (BASELINE.json configs[1])",
-                "samples_per_gpu": n, "in": "i16", "out": "i16", "shift_hz": SHIFT, "samplerate": RATE,
-                "sharding": "independent time-chunk per rank, counter seeded from the closed form; no data-path collective",
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "kernel": "dpx::rows_kernel<i16,i16>", "avg_launch_ms": round(avg_kernel_ms, 4),
-                "algorithmic_bytes_per_launch": n * BYTES_PER_SAMPLE,
-                "timing": "one HIP event pair on the launch stream around the K timed launches / K (includes the ~1.5 us inter-launch gap)",
-                "traffic_source": traffic_src,
-            },
-        }
-        if gather:
-            result["gather"] = gather
+        result = build_result(args, world, n, elapsed, avg_kernel_ms, gather)
         if world == 1:
             # PCIe-inclusive figure (never `value`): pinned host -> HBM -> kernel -> pinned host
             try:

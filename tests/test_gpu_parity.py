@@ -339,6 +339,39 @@ def test_walk_kernel_plans_vs_oracle(ctx, orc, intype, outtype):
     assert_same_bytes(got, want, outtype, "forced walk %s->%s" % (intype, outtype))
 
 
+def test_walk_kernel_random_plans(ctx, orc):
+    """Seeded random track-shaped plans: 9-30 segments of 0.05-1.3 s with arbitrary f32 shifts, random rate,
+    format pair and counter start — whatever mixture of walk matrices, leftover ranges and tile launches the
+    planner picks (auto, or forced onto the walk kernel) must reproduce the oracle byte for byte."""
+    import doppler_amd
+    rng = np.random.default_rng(4242)
+    used_walk = 0
+    for case in range(16):
+        rate = int(rng.choice([48000, 96000, 256000, 300000]))
+        segs = []
+        for _ in range(int(rng.integers(9, 31))):
+            kind = rng.integers(0, 3)
+            hz = (float(np.float32(rng.uniform(-11000, 11000))) if kind == 0 else
+                  float(np.float32(rng.integers(-400, 400) * 25)) if kind == 1 else float(np.float32(rng.uniform(-40, 40))))
+            segs.append((int(rate * rng.uniform(0.05, 1.3)) // 2048 * 2048 + (0 if rng.random() < 0.8 else int(rng.integers(1, 2048))), hz))
+        segs = [(c, h) for c, h in segs if c > 0]
+        intype, outtype = [("i16", "i16"), ("f32", "i16"), ("i16", "f32"), ("f32", "f32")][case % 4]
+        sn0 = int(rng.choice([0, 1, 12345]))
+        variant = 5 if case % 3 == 0 else 3
+        used_walk += doppler_amd.plan_layout(segs, rate, sn0, variant=variant)["walk_launches"]
+        n = sum(c for c, _ in segs)
+        x = make_iq(intype, n, 7000 + case, full_scale=(case % 2 == 0))
+        want, sn = oracle_segments(orc, x, intype, outtype, segs, rate, sn0)
+        ctx.set_tuning(0, 0, variant)
+        try:
+            got, fin = run_bulk(ctx, x, intype, outtype, segs, rate, sn0=sn0)
+        finally:
+            ctx.set_tuning(0, 0, 3)
+        assert fin == sn, (case, segs[:3])
+        assert_same_bytes(got, want, outtype, "random walk plan %d (%d segments, %s->%s)" % (case, len(segs), intype, outtype))
+    assert used_walk >= 5      # many of these plans really run on the walk kernel
+
+
 def test_chunked_equals_whole(ctx, orc):
     """Time-chunk sharding: 5 block-aligned chunks seeded from the closed form reproduce
     the single-pass output byte for byte."""
