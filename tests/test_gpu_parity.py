@@ -406,6 +406,51 @@ def test_full_size_headline_config(ctx, orc):
         assert np.array_equal(got[a:a + (1 << 28)], want[a:a + (1 << 28)]), "mismatch in slab at byte %d" % a
 
 
+def test_full_size_config0_f32_stream(ctx, orc):
+    """BASELINE.json configs[0] at full size: 64 MiB of f32 IQ (8 388 608 samples), -15000 Hz at 256 ksps, f32 out."""
+    n = 8388608
+    x = make_iq("f32", n, 1)
+    got, fin = run_bulk(ctx, x, "f32", "f32", [(n, -15000.0)], 256000)
+    want, sn = orc.const_stream(x, "f32", "f32", -15000, 256000)
+    assert fin == sn
+    assert_same_bytes(got, want, "f32", "configs[0]")
+
+
+def test_full_size_track_replay(ctx, orc):
+    """BASELINE.json configs[2] at full size: the 10-minute replay of bench.py --workload track (614 400 000 samples of
+    i16 IQ, 600 one-second shifts from the host SGP4 + the reference's schedule), one walk-kernel launch, compared byte
+    for byte with the oracle: every segment evaluated by the oracle's convert / shift_frequency / pack from the sequential counter the
+    oracle itself carries across the segments (segments run on all host cores)."""
+    import calendar
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import doppler_amd
+    rate = 1024000
+    segs = bench.track_segments(600, rate, "i16", calendar.timegm((2015, 1, 22, 19, 48, 0)))
+    n = sum(c for c, _ in segs)
+    assert n == 600 * rate and doppler_amd.plan_layout(segs, rate)["walk_launches"] == 1
+    rng = np.random.default_rng(3)
+    x = rng.integers(-23170, 23171, size=2 * n, dtype=np.int16).view(np.uint8)
+    got, fin = run_bulk(ctx, x, "i16", "i16", segs, rate)
+    seeds, sn, pos = [], 0, 0
+    for cnt, hz in segs:
+        seeds.append((pos, cnt, hz, sn))
+        sn = orc.advance_samplenum(sn, hz, rate, cnt)
+        pos += cnt
+    assert fin == sn
+
+    def check(seg):
+        pos, cnt, hz, sn0 = seg
+        o, _ = orc.shift_frequency(orc.convert_iqi16_to_complex(x[4 * pos:4 * (pos + cnt)]), sn0, hz, rate)
+        return np.array_equal(orc.pack_i16(o), got[4 * pos:4 * (pos + cnt)])
+
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 1, 64)) as pool:
+        ok = list(pool.map(check, seeds))
+    assert all(ok), "segments that differ: %r" % [i for i, o in enumerate(ok) if not o][:10]
+
+
 def test_special_values_and_degenerate_ratios(ctx, orc):
     """f32 inputs with NaN / inf / subnormals / signed zeros / huge magnitudes, i16 full-scale corners, and
     ratios that are inf or NaN (samplerate 0): outputs equal the oracle's (any NaN matches any NaN)."""
