@@ -401,13 +401,13 @@ template <int IN_FMT, int OUT_FMT> struct WalkVec {
     static constexpr bool kTranspose = IN_FMT == DPX_FMT_F32 && OUT_FMT == DPX_FMT_I16;
 };
 
-template <int IN_FMT, int OUT_FMT, bool FMA, int WAVES, int U>
+template <int IN_FMT, int OUT_FMT, bool FMA, int WAVES, int U, bool COMPUTE>
 __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restrict__ in,
                                                             uint8_t *__restrict__ out,
                                                             const float2 *__restrict__ lut_pool,
                                                             const WalkSeg *__restrict__ wsegs,
                                                             const uint32_t *__restrict__ whint,
-                                                            uint32_t n_walk_wg,
+                                                            uint32_t n_left_wg,
                                                             uint8_t *__restrict__ sink,
                                                             // ---- leftover path only
                                                             const LeftRange *__restrict__ left,
@@ -423,9 +423,12 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
     constexpr bool XP = WalkVec<IN_FMT, OUT_FMT>::kTranspose;
     __shared__ float2 slice[kWalkSlice];
     __shared__ uint32_t xpose[XP ? WAVES * U * (int)kWalkWindow : 1];   // packed i16 samples of one row per (wavefront, u)
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
 
-    if (b < n_walk_wg) {
+    // the leftover workgroups come first in the grid: their sincos work then overlaps the memory-bound matrices
+    // instead of forming a tail
+    if (blockIdx.x >= n_left_wg) {
+        const uint32_t b = blockIdx.x - n_left_wg;
         const uint32_t lane = tid & (kRowsLanes - 1), wave = tid / kRowsLanes;
         uint32_t wi = whint[b >> kWalkHintShift];
         while (wsegs[wi + 1].wg_base <= b) ++wi;                  // the list ends with a sentinel
@@ -433,16 +436,21 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
         const uint32_t w = b - ws.wg_base;
         if (w >= ws.nw) return;                                   // chunks are padded to a multiple of 8 workgroups
 
-        // this window's slice of the table: entry j = corrector of column 256 w + j - kWalkPad
-        const float2 *tab = lut_pool + ws.tab_off + w * kWalkWindow;
+        // this window's slice of correctors: entry j = corrector of column 256 w + j - kWalkPad.
+        // COMPUTE: thread j evaluates entry j (threads 0..31 also entry 256 + j) with the bit-exact sincos — after the
+        // sample loads below have been issued, so the evaluation runs in the shadow of the HBM latency.
+        // Otherwise the entries come from the plan-time table.
         constexpr int TL = ((int)kWalkSlice / 2 + THREADS - 1) / THREADS;   // 16-byte pieces per thread: 1 (2 for 128 threads)
         float2 t0[TL], t1[TL];
+        if constexpr (!COMPUTE) {
+            const float2 *tab = lut_pool + ws.tab_off + w * kWalkWindow;
 #pragma unroll
-        for (int i = 0; i < TL; ++i) {
-            const uint32_t j = tid + (uint32_t)i * THREADS;
-            if (j < kWalkSlice / 2) {
-                t0[i] = tab[2 * j];
-                t1[i] = tab[2 * j + 1];
+            for (int i = 0; i < TL; ++i) {
+                const uint32_t j = tid + (uint32_t)i * THREADS;
+                if (j < kWalkSlice / 2) {
+                    t0[i] = tab[2 * j];
+                    t1[i] = tab[2 * j + 1];
+                }
             }
         }
 
@@ -473,12 +481,32 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
             opx[u] = c4 < rowlen ? out + (row0 + c4) * OB : sink + tid * 16;
         }
 
+        if constexpr (COMPUTE) {
+            const uint32_t P = ws.period;
+            // counter of column c: ((phase + c) mod P) + 1, c = 256 w + j - kWalkPad >= -kWalkPad
+            const uint32_t ub = ws.phase + w * kWalkWindow;       // < period + L + 255 < 2^24
+            for (uint32_t j = tid; j < kWalkSlice; j += THREADS) {
+                uint32_t t;
+                if (ws.L == P) {                                  // P >= kWalkMinL > kWalkPad: at most two wraps
+                    t = ub + j + P - kWalkPad;
+                    t = t >= 2u * P ? t - 2u * P : t;
+                    t = t >= P ? t - P : t;
+                    t = t >= P ? t - P : t;
+                } else {
+                    t = (uint32_t)(((uint64_t)ub + j + (uint64_t)P * kWalkPad - kWalkPad) % P);
+                }
+                float c, sn;
+                corrector<FMA>(ws.ratio, t + 1u, c, sn);
+                slice[j] = make_float2(c, sn);
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < TL; ++i) {
-            const uint32_t j = tid + (uint32_t)i * THREADS;
-            if (j < kWalkSlice / 2) {
-                slice[2 * j] = t0[i];
-                slice[2 * j + 1] = t1[i];
+            for (int i = 0; i < TL; ++i) {
+                const uint32_t j = tid + (uint32_t)i * THREADS;
+                if (j < kWalkSlice / 2) {
+                    slice[2 * j] = t0[i];
+                    slice[2 * j + 1] = t1[i];
+                }
             }
         }
         __syncthreads();
@@ -535,7 +563,7 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
         }
     } else {
         // ---- leftover ranges: one block of kLeftBlock samples of ONE stretch, sincos per sample
-        const uint32_t e = b - n_walk_wg;
+        const uint32_t e = blockIdx.x;
         uint32_t li = lhint[e >> kLeftHintShift];
         while (left[li + 1].wg_off <= e) ++li;                    // sentinel at the end
         const LeftRange lr = left[li];
@@ -730,13 +758,13 @@ static int walk_t(const void *d_in, void *d_out, const DevSeg *d_segs, const voi
     if (n_wg == 0) return DPX_OK;
     if (n_wg > 0x7fffffffull) return DPX_ERR_ARG;
     const dim3 grid((uint32_t)n_wg);
-#define DPX_WALK_CASE(WW, UU)                                                                                                              \
-    if (w.waves == WW && w.rows_per_wave == UU) {                                                                                         \
-        if (fma) walk_kernel<IN_FMT, OUT_FMT, true, WW, UU><<<grid, WW * 64, 0, st>>>(in, out, lut, d_walk, d_whint, w.n_walk_wg, sink, d_left, d_lhint, d_segs);  \
-        else     walk_kernel<IN_FMT, OUT_FMT, false, WW, UU><<<grid, WW * 64, 0, st>>>(in, out, lut, d_walk, d_whint, w.n_walk_wg, sink, d_left, d_lhint, d_segs); \
+#define DPX_WALK_CASE(WW, UU, CC)                                                                                                          \
+    if (w.waves == WW && w.rows_per_wave == UU && (w.compute_slice != 0) == CC) {                                                         \
+        if (fma) walk_kernel<IN_FMT, OUT_FMT, true, WW, UU, CC><<<grid, WW * 64, 0, st>>>(in, out, lut, d_walk, d_whint, w.n_left_wg, sink, d_left, d_lhint, d_segs);  \
+        else     walk_kernel<IN_FMT, OUT_FMT, false, WW, UU, CC><<<grid, WW * 64, 0, st>>>(in, out, lut, d_walk, d_whint, w.n_left_wg, sink, d_left, d_lhint, d_segs); \
         return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                                                    \
     }
-    DPX_WALK_CASE(4, 2) DPX_WALK_CASE(4, 4) DPX_WALK_CASE(8, 2) DPX_WALK_CASE(4, 1) DPX_WALK_CASE(8, 1) DPX_WALK_CASE(2, 2) DPX_WALK_CASE(2, 4)
+    DPX_WALK_CASE(4, 2, true) DPX_WALK_CASE(4, 2, false) DPX_WALK_CASE(8, 2, true) DPX_WALK_CASE(8, 1, true) DPX_WALK_CASE(2, 2, true)
 #undef DPX_WALK_CASE
     return DPX_ERR_ARG;
 }

@@ -195,6 +195,16 @@ WalkShape walk_shape()
     return shape;
 }
 
+// The walk kernel's workgroups read their 288 correctors from plan-time tables (default), or evaluate them themselves
+// with the bit-exact sincos while their sample loads are in flight (DPX_WALK_COMPUTE=1: no tables, no table traffic).
+// Measured on the 600 s replay: tables 5430 GB/s, on-the-fly 5200 GB/s (median; its best launches match) — the f64
+// work costs more than the 16 % of extra reads it removes.
+bool walk_computes_slices()
+{
+    static const bool compute = [] { const char *e = getenv("DPX_WALK_COMPUTE"); return e && atoi(e) != 0; }();
+    return compute;
+}
+
 // matrix of the walk kernel for one stretch (dpx_types.h, WalkSeg); false if the stretch does not qualify
 bool walk_geometry(const DevSeg &s, WalkSeg *w)
 {
@@ -217,7 +227,10 @@ bool walk_geometry(const DevSeg &s, WalkSeg *w)
     w->nw = (uint32_t)nw;
     w->rows = (uint32_t)rows;
     w->row0 = 0;
-    w->pad[0] = w->pad[1] = 0;
+    w->period = s.period;
+    w->phase = counter_at(s, A - s.first) - 1u;
+    w->ratio = s.ratio;
+    w->pad[0] = w->pad[1] = w->pad[2] = 0;
     return true;
 }
 
@@ -362,14 +375,16 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
                 continue;
             }
             s.flags |= kSegWalk;
-            w.tab_off = (uint32_t)pool;
-            // entry x = corrector of column x - kWalkPad, column 0 = sample A
-            const uint32_t P = s.period;
-            const uint32_t phase_a = counter_at(s, w.A - s.first) - 1u;
-            const uint32_t n_first = (uint32_t)(((uint64_t)phase_a + (uint64_t)P * kWalkPad - kWalkPad) % P) + 1u;
-            const uint32_t n_entries = w.nw * kWalkWindow + kWalkPad;     // every window reads a whole 288-entry slice
-            plan.tables.push_back({pool, P, n_first, n_entries, s.ratio});
-            pool += ((uint64_t)n_entries + 3) & ~3ull;
+            w.tab_off = 0;
+            if (!walk_computes_slices()) {
+                // entry x = corrector of column x - kWalkPad, column 0 = sample A
+                w.tab_off = (uint32_t)pool;
+                const uint32_t P = s.period;
+                const uint32_t n_first = (uint32_t)(((uint64_t)w.phase + (uint64_t)P * kWalkPad - kWalkPad) % P) + 1u;
+                const uint32_t n_entries = w.nw * kWalkWindow + kWalkPad;     // every window reads a whole 288-entry slice
+                plan.tables.push_back({pool, P, n_first, n_entries, s.ratio});
+                pool += ((uint64_t)n_entries + 3) & ~3ull;
+            }
             mats.push_back(w);
             if (s.first < w.A) pieces.push_back({s.first, w.A, (uint32_t)i});
             if (w.E < end) pieces.push_back({w.E, end, (uint32_t)i});
@@ -423,6 +438,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
         ln.walk.n_segs = (uint32_t)ns;
         ln.walk.waves = walk_shape().waves;
         ln.walk.rows_per_wave = walk_shape().rows_per_wave;
+        ln.walk.compute_slice = walk_computes_slices() ? 1u : 0u;
         plan.launches.push_back(ln);
         // sentinels end the kernels' forward scans; hints give the scan its starting point
         WalkSeg wend;
@@ -559,8 +575,26 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
                     for (uint32_t cl = 0; cl < kWalkWindow; ++cl) {
                         const uint32_t c = w * kWalkWindow + cl;
                         if (c >= rowlen) break;                                   // lanes past the row store to the sink
-                        const uint32_t x = w * kWalkWindow + (kWalkPad - delta + cl);   // slice base + index in the slice
-                        if (kWalkPad - delta + cl >= kWalkSlice || x >= tb->n_entries) { put(row0 + c, 0xffffffffu); continue; }
+                        const uint32_t j = kWalkPad - delta + cl;                 // index in the slice
+                        if (j >= kWalkSlice) { put(row0 + c, 0xffffffffu); continue; }
+                        if (wa.compute_slice) {                                   // the kernel's own counter arithmetic
+                            const uint32_t P = ws.period;
+                            const uint32_t ub = ws.phase + w * kWalkWindow;
+                            uint32_t t;
+                            if (ws.L == P) {
+                                t = ub + j + P - kWalkPad;
+                                t = t >= 2u * P ? t - 2u * P : t;
+                                t = t >= P ? t - P : t;
+                                t = t >= P ? t - P : t;
+                                if (t >= P) { put(row0 + c, 0xfffffffdu); continue; }
+                            } else {
+                                t = (uint32_t)(((uint64_t)ub + j + (uint64_t)P * kWalkPad - kWalkPad) % P);
+                            }
+                            put(row0 + c, t + 1u);
+                            continue;
+                        }
+                        const uint32_t x = w * kWalkWindow + j;                   // table index
+                        if (x >= tb->n_entries) { put(row0 + c, 0xffffffffu); continue; }
                         put(row0 + c, (uint32_t)(((uint64_t)(tb->n_first - 1u) + x) % tb->period) + 1u);
                     }
                 }

@@ -79,8 +79,9 @@ struct RowsArgs {
 // A stretch [A, E) is viewed as rows of L samples (L a multiple of the period), row r starting at the 32-sample
 // boundary at or below A + r * L, so every wavefront access is a whole number of 128-byte lines whatever the
 // period.  A workgroup takes one 256-sample column window of eight consecutive rows (4 wavefronts x 2 rows): the
-// window's correctors are read once and shared through LDS (the tile kernel reads 8 bytes of table per sample,
-// cold, because all tiles of a one-second stretch are in flight at once).  Row r is shifted left by
+// window's 288 correctors are fetched once from a plan-time table (or, as a measured alternative, evaluated by the
+// workgroup itself while its sample loads are in flight) and shared through LDS (the tile kernel reads 8 bytes of
+// table per sample, cold, because all tiles of a one-second stretch are in flight at once).  Row r is shifted left by
 // delta_r = (A + r * L) mod 32 samples, so its lanes index the table at kWalkPad - delta_r + column.
 // The launch is a list of row chunks (WalkSeg), stretch by stretch, each chunk padded to a multiple of 8 workgroups.
 struct WalkSeg {           // one row chunk (kWalkWaves x kWalkRowsPerWave rows) of one stretch's matrix
@@ -92,9 +93,12 @@ struct WalkSeg {           // one row chunk (kWalkWaves x kWalkRowsPerWave rows)
     uint32_t nw;           // column windows per row
     uint32_t rows;         // rows of the matrix
     uint32_t row0;         // first row of this chunk
-    uint32_t pad[2];
+    uint32_t period;       // of the stretch (L is a multiple of it)
+    uint32_t phase;        // counter of sample A, minus 1: column c uses counter ((phase + c) mod period) + 1
+    float ratio;           // of the stretch (dsp.rs:121)
+    uint32_t pad[3];
 };
-static_assert(sizeof(WalkSeg) == 48, "WalkSeg is read with scalar loads");
+static_assert(sizeof(WalkSeg) == 64, "WalkSeg is read with scalar loads");
 
 // what the walk kernel's matrices do not cover (heads, tails, lead-ins, untabulated stretches too short for
 // a tile launch): ranges inside ONE stretch each, evaluated sample by sample in 256-sample blocks
@@ -123,6 +127,7 @@ struct WalkArgs {
     uint32_t n_left_wg;    // workgroups evaluating leftover ranges
     uint32_t n_segs;
     uint32_t waves, rows_per_wave;   // workgroup geometry the descriptors were laid out for
+    uint32_t compute_slice;          // 1: workgroups evaluate their 288 correctors themselves (no tables); 0: read them
 };
 
 struct TileArgs {
