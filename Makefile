@@ -54,6 +54,14 @@ tests/cpp/test_dsp: tests/cpp/test_dsp.cpp include/doppler_dsp.hpp include/doppl
 
 cpptest: tests/cpp/test_dsp
 
+# host-only fuzz of the planner under AddressSanitizer + UBSan (no GPU, no HIP)
+tests/cpp/test_planner_fuzz: tests/cpp/test_planner_fuzz.cpp $(CSRC)/dpx_planner.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h
+	g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -ffp-contract=off -fno-fast-math -Wall \
+	    -o $@ tests/cpp/test_planner_fuzz.cpp $(CSRC)/dpx_planner.cpp
+
+planner-fuzz: tests/cpp/test_planner_fuzz
+	tests/cpp/test_planner_fuzz 300
+
 oracle:
 	$(MAKE) -C oracle all
 
@@ -61,4 +69,4 @@ clean:
 	rm -rf $(LIBDIR) $(BINDIR)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib cli oracle cpptest clean
+.PHONY: all lib cli oracle cpptest planner-fuzz clean

@@ -450,14 +450,14 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
         plan.walk_hint.assign(n_wh, 0);
         uint32_t wi = 0;
         for (uint64_t h = 0; h < n_wh; ++h) {
-            while (plan.walk[wi + 1].wg_base <= (h << kWalkHintShift)) ++wi;
+            while (wi + 2 < plan.walk.size() && plan.walk[wi + 1].wg_base <= (h << kWalkHintShift)) ++wi;
             plan.walk_hint[h] = wi;
         }
         const uint64_t n_lh = (left_wg >> kLeftHintShift) + 1;
         plan.left_hint.assign(n_lh, 0);
         uint32_t li = 0;
         for (uint64_t h = 0; h < n_lh; ++h) {
-            while (plan.left[li + 1].wg_off <= (h << kLeftHintShift)) ++li;
+            while (li + 2 < plan.left.size() && plan.left[li + 1].wg_off <= (h << kLeftHintShift)) ++li;
             plan.left_hint[h] = li;
         }
     }

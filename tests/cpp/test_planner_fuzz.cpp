@@ -1,0 +1,87 @@
+// Host-only fuzz of the planner (csrc/dpx_planner.cpp), built with -fsanitize=address,undefined by `make planner-fuzz`:
+// random const- and track-shaped segment lists -> plan_append -> finalize (every KernelChoice) -> simulate; every sample
+// must be produced exactly once with the counter of the sequential rule (dsp.rs:125-130), and the sanitizers must stay
+// silent (the hint / sentinel scans index vectors by hand).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../doppler_amd/csrc/dpx_planner.h"
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t rnd()
+{
+    rng_state ^= rng_state << 13;
+    rng_state ^= rng_state >> 7;
+    rng_state ^= rng_state << 17;
+    return rng_state;
+}
+static double uni() { return (double)(rnd() >> 11) / 9007199254740992.0; }
+
+int main(int argc, char **argv)
+{
+    const int cases = argc > 1 ? atoi(argv[1]) : 400;
+    const uint32_t rates[] = {8000, 48000, 256000, 1024000, 300000};
+    long checked = 0;
+    for (int c = 0; c < cases; ++c) {
+        const uint32_t rate = rates[rnd() % 5];
+        const int nseg = 1 + (int)(rnd() % (c % 3 == 0 ? 14 : 3));
+        std::vector<std::pair<uint64_t, float>> segs;
+        for (int i = 0; i < nseg; ++i) {
+            float hz;
+            switch (rnd() % 4) {
+            case 0: hz = (float)((int)(rnd() % 40000) - 20000); break;
+            case 1: hz = (float)(uni() * 24000.0 - 12000.0); break;
+            case 2: hz = (float)rate / (float)(2 + rnd() % 1000); break;
+            default: hz = (float)(uni() * 6.0 - 3.0); break;
+            }
+            uint64_t cnt;
+            switch (rnd() % 5) {
+            case 0: cnt = 1 + rnd() % 5000; break;
+            case 1: cnt = 2048 * (1 + rnd() % 64); break;          // whole blocks: aligned stretches, no heads or tails
+            case 2: cnt = 16384 * (1 + rnd() % 8); break;
+            case 3: cnt = 60000 + rnd() % 40000; break;
+            default: cnt = 32 * (1 + rnd() % 4000); break;
+            }
+            segs.push_back({cnt, hz});
+        }
+        const uint32_t sn0s[] = {0, 1, 2, 1000, 65535, 1u << 20};
+        const uint32_t sn0 = sn0s[rnd() % 6];
+        // the sequential rule
+        std::vector<uint32_t> want;
+        {
+            uint32_t n = sn0;
+            for (auto &sg : segs) {
+                const float ratio = dpx::ratio_of(sg.second, rate);
+                for (uint64_t k = 0; k < sg.first; ++k) {
+                    want.push_back(n);
+                    n = dpx::is_reset(ratio, n) ? 1u : n + 1u;
+                }
+            }
+        }
+        for (int choice = 0; choice < 4; ++choice) {
+            dpx::PlanResult plan;
+            uint32_t sn = sn0;
+            for (auto &sg : segs) dpx::plan_append(plan, dpx::ratio_of(sg.second, rate), sg.first, sn, 0);
+            const uint32_t tile = (c & 1) ? 1024 : 512;
+            dpx::finalize(plan, tile, choice);
+            if (plan.error) { fprintf(stderr, "case %d: %s\n", c, plan.error); return 1; }
+            std::vector<uint32_t> got(plan.n_samples + 1, 0);
+            std::vector<uint8_t> writes(plan.n_samples + 1, 0);
+            dpx::simulate(plan, got.data(), writes.data());
+            for (uint64_t g = 0; g < plan.n_samples; ++g) {
+                if (writes[g] != 1 || got[g] != want[g]) {
+                    fprintf(stderr, "case %d choice %d: sample %llu written %u times, counter %u, want %u\n", c, choice,
+                            (unsigned long long)g, writes[g], got[g], want[g]);
+                    return 1;
+                }
+            }
+            checked += (long)plan.n_samples;
+        }
+    }
+    printf("planner fuzz: %d cases x 4 kernel choices, %ld samples checked, ok\n", cases, checked);
+    return 0;
+}

@@ -339,6 +339,20 @@ def test_walk_kernel_plans_vs_oracle(ctx, orc, intype, outtype):
     assert_same_bytes(got, want, outtype, "forced walk %s->%s" % (intype, outtype))
 
 
+def test_walk_kernel_on_the_fly_slices():
+    """DPX_WALK_COMPUTE=1 (read once per process): the walk kernel's workgroups evaluate their corrector slices
+    themselves instead of reading plan-time tables.  Same parity bar; run in a child process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DPX_WALK_COMPUTE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        "-k", "walk_kernel_plans_vs_oracle or walk_kernel_random_plans"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_walk_kernel_random_plans(ctx, orc):
     """Seeded random track-shaped plans: 9-30 segments of 0.05-1.3 s with arbitrary f32 shifts, random rate,
     format pair and counter start — whatever mixture of walk matrices, leftover ranges and tile launches the

@@ -129,6 +129,21 @@ def test_walk_kernel_plans(orc):
             assert np.array_equal(c, want), (segs[:3], variant, np.flatnonzero(c != want)[:5])
 
 
+def test_planner_fuzz_under_sanitizers():
+    """tests/cpp/test_planner_fuzz.cpp: random plans through plan_append / finalize (all kernel choices) / simulate with
+    the planner compiled under AddressSanitizer + UBSan — the hint and sentinel scans index vectors by hand, and an
+    out-of-bounds read there only shows as a rare crash of the `doppler` command otherwise."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", root, "tests/cpp/test_planner_fuzz"], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in (r.stderr + r.stdout):
+        pytest.skip("no sanitizer runtime for g++ here")
+    assert r.returncode == 0, r.stderr[-1500:]
+    r = subprocess.run([os.path.join(root, "tests", "cpp", "test_planner_fuzz"), "250"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "ok" in r.stdout
+
+
 def test_chunk_sharding_seeds(orc):
     n = 2048 * 37 + 555
     for world in (1, 2, 3, 8):
