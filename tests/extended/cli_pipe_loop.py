@@ -1,6 +1,10 @@
-"""Loops the `doppler track` invocation of tests/test_gpu_cli.py exactly as the test runs it (subprocess pipes)."""
+"""Loops the `doppler track` invocation of tests/test_gpu_cli.py exactly as the test runs it (subprocess pipes: pipe
+timing cuts the stream into different slabs every run).  `python tests/extended/cli_pipe_loop.py 100 [gdb]`.
+Found the out-of-bounds hint scan fixed in round 1 (7 crashes in 160 runs before, 0 in 200 after)."""
 import os, subprocess, sys
-sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.chdir(ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from helpers import make_iq
 EXE = "doppler_amd/bin/doppler"

@@ -3,7 +3,7 @@ restated glibc sincosf for ALL 2^32 float bit patterns, and against this host's 
 reference's complex.c when oracle/_ref is built) for the build the host selects.  Prints one JSON line."""
 import json, os, sys, time
 from concurrent.futures import ThreadPoolExecutor
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import doppler_amd
 from doppler_amd import dsp

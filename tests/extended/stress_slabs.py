@@ -1,7 +1,9 @@
 """Stress: the track-replay stream of tests/test_gpu_cli.py cut into slabs at random block boundaries (what pipe timing
 does to the `doppler` command), every cut pattern through the dpx_stream_* ring, compared with the oracle."""
 import sys
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import doppler_amd
 from helpers import make_iq
