@@ -56,6 +56,10 @@ struct dpx_ctx {
     void *stage_out = nullptr;
     size_t stage_in_cap = 0, stage_out_cap = 0;
     struct DevPlan *scratch = nullptr;   // device side of the host-pointer operators' plans
+    // small calls (the reference's own 8 KiB block): one pinned, device-mapped host buffer holds input, output and
+    // the plan image; the kernel reads and writes it over PCIe directly, so a call is memcpy + one launch + one wait
+    char *small_host = nullptr;
+    char *small_dev = nullptr;
 };
 
 // device image of a plan: stretch table | hint table | corrector-table pool, one allocation
@@ -70,6 +74,7 @@ struct DevPlan {
     uint32_t *left_hint = nullptr;
     void *sink = nullptr;          // where walk-kernel lanes without a sample store
     void *lut = nullptr;
+    std::vector<char> image;       // host copy of everything before `sink`, source of the one upload
 };
 
 struct dpx_plan {
@@ -154,20 +159,19 @@ int materialize(dpx_ctx *ctx, const dpx::PlanResult &plan, DevPlan &dev, bool fm
     dev.left_hint = reinterpret_cast<uint32_t *>(p);         p += lhint_bytes;
     dev.sink = p;                                            p += sink_bytes;
     dev.lut = p;
-    if (!plan.walk.empty()) {
-        DPX_HIP(hipMemcpyAsync(dev.walk, plan.walk.data(), plan.walk.size() * sizeof(dpx::WalkSeg),
-                               hipMemcpyHostToDevice, st));
-        DPX_HIP(hipMemcpyAsync(dev.walk_hint, plan.walk_hint.data(), plan.walk_hint.size() * sizeof(uint32_t),
-                               hipMemcpyHostToDevice, st));
-        DPX_HIP(hipMemcpyAsync(dev.left, plan.left.data(), plan.left.size() * sizeof(dpx::LeftRange),
-                               hipMemcpyHostToDevice, st));
-        DPX_HIP(hipMemcpyAsync(dev.left_hint, plan.left_hint.data(), plan.left_hint.size() * sizeof(uint32_t),
-                               hipMemcpyHostToDevice, st));
-    }
-    DPX_HIP(hipMemcpyAsync(dev.segs, plan.segs.data(), plan.segs.size() * sizeof(dpx::DevSeg),
-                           hipMemcpyHostToDevice, st));
-    DPX_HIP(hipMemcpyAsync(dev.hint, plan.hint.data(), plan.hint.size() * sizeof(uint32_t),
-                           hipMemcpyHostToDevice, st));
+    // one host image of all the small tables, one copy (every hipMemcpyAsync from pageable memory costs 5-8 us)
+    const size_t image_bytes = seg_bytes + hint_bytes + walk_bytes + whint_bytes + left_bytes + lhint_bytes;
+    dev.image.assign(image_bytes, 0);
+    char *img = dev.image.data();
+    auto put = [&](size_t off, const void *src, size_t bytes) { if (bytes) memcpy(img + off, src, bytes); };
+    size_t off = 0;
+    put(off, plan.segs.data(), plan.segs.size() * sizeof(dpx::DevSeg));              off += seg_bytes;
+    put(off, plan.hint.data(), plan.hint.size() * sizeof(uint32_t));                 off += hint_bytes;
+    put(off, plan.walk.data(), plan.walk.size() * sizeof(dpx::WalkSeg));             off += walk_bytes;
+    put(off, plan.walk_hint.data(), plan.walk_hint.size() * sizeof(uint32_t));       off += whint_bytes;
+    put(off, plan.left.data(), plan.left.size() * sizeof(dpx::LeftRange));           off += left_bytes;
+    put(off, plan.left_hint.data(), plan.left_hint.size() * sizeof(uint32_t));
+    DPX_HIP(hipMemcpyAsync(base, img, image_bytes, hipMemcpyHostToDevice, st));
     for (const dpx::TableBuild &t : plan.tables) {
         int rc = dpx::launch_build_lut(static_cast<char *>(dev.lut) + (size_t)t.off * 8, t.period, t.n_first,
                                        t.n_entries, t.ratio, fma, st);
@@ -201,11 +205,62 @@ void release(DevPlan &dev)
     dev = DevPlan();
 }
 
+constexpr size_t kSmallCallBytes = 64 << 10;      // per side; larger calls go through device staging buffers
+constexpr size_t kSmallPlanBytes = 16 << 10;
+constexpr size_t kSmallInOff = 0, kSmallOutOff = kSmallCallBytes, kSmallPlanOff = 2 * kSmallCallBytes;
+
+// One 8 KiB block per call is what the reference's loop does (main.rs:62-99).  For such calls the fixed costs decide:
+// no device staging, no hipMemcpy calls, no corrector tables (2048 samples do not pay for a table build) — the tile
+// kernel reads the samples and the two plan tables from pinned host memory and writes the result there.
+int run_host_small(dpx_ctx *ctx, const void *in, size_t n, int in_fmt, void *out, int out_fmt,
+                   uint32_t *samplenum, float shift_hz, uint32_t samplerate)
+{
+    if (!ctx->small_host) {
+        void *h = nullptr, *d = nullptr;
+        DPX_HIP(hipHostMalloc(&h, 2 * kSmallCallBytes + kSmallPlanBytes, hipHostMallocMapped));
+        hipError_t e = hipHostGetDevicePointer(&d, h, 0);
+        if (e != hipSuccess) {
+            (void)hipHostFree(h);
+            return fail(DPX_ERR_HIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(e));
+        }
+        ctx->small_host = static_cast<char *>(h);
+        ctx->small_dev = static_cast<char *>(d);
+    }
+    dpx::PlanResult plan;
+    uint32_t sn = *samplenum;
+    dpx::plan_append(plan, dpx::ratio_of(shift_hz, samplerate), n, sn, 1 /* sincos per sample */);
+    const dpx::LaunchGeom g = geometry(ctx);
+    dpx::finalize(plan, g.tile(), dpx::kChooseTileOnly);
+    if (plan.error) return fail(DPX_ERR_PLAN, "%s", plan.error);
+    const size_t seg_bytes = align256(plan.segs.size() * sizeof(dpx::DevSeg));
+    const size_t hint_bytes = plan.hint.size() * sizeof(uint32_t);
+    if (plan.lut_entries != 0 || seg_bytes + hint_bytes > kSmallPlanBytes) return 1;   // caller takes the general path
+    const size_t in_bytes = n * bytes_per_sample(in_fmt), out_bytes = n * bytes_per_sample(out_fmt);
+    memcpy(ctx->small_host + kSmallInOff, in, in_bytes);
+    memcpy(ctx->small_host + kSmallPlanOff, plan.segs.data(), plan.segs.size() * sizeof(dpx::DevSeg));
+    memcpy(ctx->small_host + kSmallPlanOff + seg_bytes, plan.hint.data(), hint_bytes);
+    DevPlan dev;
+    dev.segs = reinterpret_cast<dpx::DevSeg *>(ctx->small_dev + kSmallPlanOff);
+    dev.hint = reinterpret_cast<uint32_t *>(ctx->small_dev + kSmallPlanOff + seg_bytes);
+    dev.lut = ctx->small_dev + kSmallPlanOff;      // never read: no tabulated stretch in this plan
+    int rc = run_plan(plan, dev, ctx->small_dev + kSmallInOff, in_fmt, ctx->small_dev + kSmallOutOff, out_fmt, ctx->fma, g,
+                      ctx->stream);
+    if (rc != DPX_OK) return rc;
+    DPX_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->small_host + kSmallOutOff, out_bytes);
+    *samplenum = sn;
+    return DPX_OK;
+}
+
 // shared body of the host-pointer operators: stage in, one fused launch, stage out
 int run_host(dpx_ctx *ctx, const void *in, size_t n, int in_fmt, void *out, int out_fmt,
              uint32_t *samplenum, float shift_hz, uint32_t samplerate)
 {
     DPX_HIP(hipSetDevice(ctx->device));
+    if (n != 0 && n * 8 <= kSmallCallBytes && ctx->variant == 0) {
+        const int rc = run_host_small(ctx, in, n, in_fmt, out, out_fmt, samplenum, shift_hz, samplerate);
+        if (rc <= 0) return rc;
+    }
     dpx::PlanResult plan;
     uint32_t sn = *samplenum;
     dpx::plan_append(plan, dpx::ratio_of(shift_hz, samplerate), n, sn, ctx->variant);
@@ -293,6 +348,7 @@ void dpx_ctx_destroy(dpx_ctx *ctx)
         release(*ctx->scratch);
         delete ctx->scratch;
     }
+    if (ctx->small_host) (void)hipHostFree(ctx->small_host);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
