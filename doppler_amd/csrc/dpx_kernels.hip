@@ -5,6 +5,7 @@
 //     load 16-byte vectors of interleaved IQ  ->  unpack in registers
 //     corrector(n) from a precomputed table (one period) or evaluated on the fly
 //     complex multiply with the reference's unfused f32 operation order
+//       (three packed instructions, each product and the sum rounded on its own)
 //     pack to i16 / f32  ->  16-byte stores
 // The kernel is HBM-bandwidth bound by design: 8 B/sample for i16->i16.
 // No MFMA: there is no contraction anywhere in this path.
@@ -164,14 +165,17 @@ __device__ __forceinline__ uint32_t counter_at(const DevSeg &sg, uint64_t j)
 // workgroups of 1-4 wavefronts that touch 1-4 KiB and exit, against 6.0-6.1 TB/s
 // for every persistent grid-stride shape tried, and every extra vector-memory
 // instruction per wavefront (a corrector table read) costs a few percent.  So:
-//   * no persistent loop, no LDS staging, tiny workgroups, addresses from
-//     blockIdx alone so the sample loads are issued first;
+//   * no persistent loop, tiny workgroups, addresses from blockIdx alone so the
+//     sample loads are issued first;
 //   * correctors of a periodic stretch are tabulated ONCE per plan in global
-//     memory (<= 64 KiB, L2-resident) by build_lut_kernel with the bit-exact
-//     sincos, never per workgroup;
-//   * rows kernel: the stream is viewed as a matrix whose row length is a
-//     multiple of the period, so the two rows a wavefront handles share one
-//     32-byte table read per lane and need no phase arithmetic.
+//     memory (one period) by build_lut_kernel with the bit-exact sincos;
+//   * rows kernel (const mode): the stream is viewed as a matrix whose row
+//     length is a multiple of the period, so the two rows a wavefront handles
+//     share one 32-byte table read per lane and need no phase arithmetic;
+//   * walk kernel (track mode, hundreds of stretches in one launch): same idea
+//     with rows shifted onto 128-byte lines and the 288 correctors of a column
+//     window shared by eight rows through LDS (the only LDS use in this file);
+//   * tile kernel: whatever the two above leave.
 
 // ---- per-sample evaluation (ragged ranges and stretch boundaries)
 template <int IN_FMT, int OUT_FMT, bool FMA>
