@@ -69,20 +69,20 @@ def ordered_gather(local, sizes, dst=0, group=None):
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     assert len(sizes) == world and local.numel() == sizes[rank]
+    # One batch (ncclGroupStart/End under RCCL): the receives from all peers are in flight together, each on its own
+    # xGMI link into `dst`, instead of one after the other.
     if rank != dst:
         if local.numel():
-            dist.send(local, dst=dst, group=group)
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, dst, group)]):
+                q.wait()
         return None
     full = torch.empty(sum(sizes), dtype=local.dtype, device=local.device)
     offs = [0]
     for s in sizes:
         offs.append(offs[-1] + s)
     full[offs[rank]:offs[rank + 1]].copy_(local)
-    reqs = []
-    for r in range(world):
-        if r == dst or sizes[r] == 0:
-            continue
-        reqs.append(dist.irecv(full[offs[r]:offs[r + 1]], src=r, group=group))
-    for q in reqs:
-        q.wait()
+    ops = [dist.P2POp(dist.irecv, full[offs[r]:offs[r + 1]], r, group) for r in range(world) if r != dst and sizes[r]]
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
     return full
