@@ -44,7 +44,7 @@ cli: $(BINDIR)/doppler
 
 $(BINDIR)/doppler: $(CSRC)/cli/main.cpp $(CSRC)/cli/args.cpp $(CSRC)/cli/args.h $(LIB)
 	@mkdir -p $(BINDIR)
-	g++ -O2 -std=c++17 -ffp-contract=off -Wall -Iinclude $(CSRC)/cli/main.cpp $(CSRC)/cli/args.cpp \
+	g++ -O2 -std=c++17 -ffp-contract=off -Wall -pthread -Iinclude $(CSRC)/cli/main.cpp $(CSRC)/cli/args.cpp \
 	    -o $@ -L$(LIBDIR) -ldoppler_hip -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,$(ROCM)/lib
 
 # the reference's in-file tests against the C++ mirror of doppler::dsp (needs the oracle as checker)

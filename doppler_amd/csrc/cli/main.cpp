@@ -22,10 +22,13 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <fstream>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/doppler_hip.h"
@@ -186,23 +189,37 @@ int main(int argc, char **argv)
 
     // three pinned slabs in rotation (include/doppler_hip.h, "streaming from host memory")
     dpx_stream *stream = nullptr;
-    DPXCHK(dpx_stream_create(ctx, in_fmt, out_fmt, args.samplerate, /*samplenr, main.rs:60*/ 0, slab_bytes, 3, &stream));
+    DPXCHK(dpx_stream_create(ctx, in_fmt, out_fmt, args.samplerate, /*samplenr, main.rs:60*/ 0, slab_bytes, 3, &stream));   // kSlabs below
 
-    auto drain_one = [&]() {            // oldest slab: wait, write to stdout, free
-        const void *out = nullptr;
-        size_t nbytes = 0;
-        DPXCHK(dpx_stream_next(stream, &out, &nbytes));
-        if (!write_all(STDOUT_FILENO, static_cast<const char *>(out), nbytes)) {
-            info("doppler stdout.write error: %s", strerror(errno));       // main.rs:86
-            exit(1);
+    // The ring is driven from two threads: this one reads stdin into slabs and submits them, the writer thread
+    // below waits for the oldest slab, writes it to stdout and frees it — read(), the GPU and write() overlap.
+    constexpr int kSlabs = 3;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t submitted = 0, drained = 0;    // guarded by mu
+    bool input_done = false;
+    std::thread writer([&]() {
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return submitted > drained || input_done; });
+                if (submitted == drained) return;       // input_done and nothing left
+            }
+            const void *out = nullptr;
+            size_t nbytes = 0;
+            DPXCHK(dpx_stream_next(stream, &out, &nbytes));
+            if (!write_all(STDOUT_FILENO, static_cast<const char *>(out), nbytes)) {
+                info("doppler stdout.write error: %s", strerror(errno));       // main.rs:86
+                exit(1);
+            }
+            DPXCHK(dpx_stream_release(stream));
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ++drained;
+            }
+            cv.notify_all();
         }
-        DPXCHK(dpx_stream_release(stream));
-    };
-    auto pending = [&]() {
-        int n = 0;
-        DPXCHK(dpx_stream_pending(stream, &n));
-        return n;
-    };
+    });
 
     // the reference's loop state
     const bool replay = args.mode == dpx::Mode::Track && args.has_time;
@@ -225,7 +242,10 @@ int main(int argc, char **argv)
     while (!eof) {
         void *buf = nullptr;
         size_t cap = 0;
-        if (pending() == 3) drain_one();   // every slab in flight: the oldest must be written out first
+        {   // every slab in flight: wait for the writer to free the oldest
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return submitted - drained < (uint64_t)kSlabs; });
+        }
         DPXCHK(dpx_stream_acquire(stream, &buf, &cap));
         const size_t n = gather(STDIN_FILENO, static_cast<char *>(buf), cap, &eof);
         // main.rs:63-68: complete blocks always; the trailing short block only if it is whole samples
@@ -287,11 +307,18 @@ int main(int argc, char **argv)
             }
         }
         DPXCHK(dpx_stream_submit(stream, use, segs.data(), segs.size()));
-        // a slab that did not fill means the producer is slower than we are (a live pipe): hand the
-        // output over now instead of when the ring comes round, so that the latency stays one slab
-        if (n < cap) while (pending()) drain_one();
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            ++submitted;
+        }
+        cv.notify_all();        // the writer hands every slab over as soon as it is done: on a live pipe the latency is one slab
     }
-    while (pending()) drain_one();
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        input_done = true;
+    }
+    cv.notify_all();
+    writer.join();
 
     if (getenv("DOPPLER_STATS")) {      // steady-state rate: first read to last write, start-up excluded
         struct timeval tv_end;

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <new>
 #include <vector>
 
@@ -734,7 +735,9 @@ struct dpx_stream_slab {
     dpx::PlanResult plan;
     DevPlan dev;
     size_t out_bytes = 0;
-    int state = 0;      // 0 free, 1 acquired (being filled), 2 in flight, 3 handed out by next()
+    std::atomic<int> state{0};   // 0 free, 1 acquired (being filled), 2 in flight, 3 handed out by next()
+    dpx_stream_slab() = default;
+    dpx_stream_slab(const dpx_stream_slab &) {}   // slabs are only ever default-constructed (vector::resize)
 };
 
 struct dpx_stream {
@@ -743,9 +746,9 @@ struct dpx_stream {
     uint32_t samplerate = 0, samplenum = 0;
     size_t slab_bytes = 0, slab_out = 0;
     std::vector<dpx_stream_slab> slabs;
-    size_t head = 0;    // next slab to acquire
-    size_t tail = 0;    // oldest submitted slab
-    int in_flight = 0;
+    size_t head = 0;    // next slab to acquire            (producer side: acquire / submit)
+    size_t tail = 0;    // oldest submitted slab           (consumer side: next / release)
+    std::atomic<int> in_flight{0};
 };
 
 int dpx_stream_create(dpx_ctx *ctx, int in_fmt, int out_fmt, uint32_t samplerate, uint32_t samplenum0,

@@ -208,7 +208,9 @@ int dpx_run_device(dpx_plan *plan, const void *d_in, int in_fmt, void *d_out, in
  *                          segments (their sample counts must add up to in_bytes); asynchronous
  *   dpx_stream_next     -> oldest submitted slab: waits for it, returns its pinned output
  *   dpx_stream_release  -> that output has been consumed; the slab is free again
- * Outputs come back in submission order. */
+ * Outputs come back in submission order.
+ * Threads: one producer thread (acquire / submit) and one consumer thread (next / release) may drive the same
+ * stream concurrently, as the `doppler` command does; any other sharing needs the caller's own lock. */
 typedef struct dpx_stream dpx_stream;
 int dpx_stream_create(dpx_ctx *ctx, int in_fmt, int out_fmt, uint32_t samplerate, uint32_t samplenum0,
                       size_t slab_bytes, int n_slabs, dpx_stream **stream);
