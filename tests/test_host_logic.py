@@ -129,6 +129,27 @@ def test_walk_kernel_plans(orc):
             assert np.array_equal(c, want), (segs[:3], variant, np.flatnonzero(c != want)[:5])
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/doppler_hip.h is the drop-in boundary: it must compile as C99 on its own (no C++, no HIP, no torch types)
+    and a C program must link against the library with nothing else."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "doppler_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) { dpx_layout l; dpx_segment s = {2048, 5000.0f}; dpx_stretch st[4]; size_t n = 0; uint32_t fin = 0;\n'
+                   '  if (dpx_plan_describe(&s, 1, 1024000, 0, 3, st, 4, &n, &fin) != DPX_OK) return 2;\n'
+                   '  if (dpx_plan_layout(&s, 1, 1024000, 0, 0, 0, 3, &l) != DPX_OK) return 3;\n'
+                   '  printf("%d %u %llu\\n", dpx_abi_version(), fin, (unsigned long long)l.n_samples); return 0; }\n')
+    exe = tmp_path / "hdr"
+    lib = os.path.join(root, "doppler_amd", "lib")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src),
+                        "-o", str(exe), "-L", lib, "-ldoppler_hip", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True)       # host-only entry points: runs without a GPU
+    assert r.returncode == 0 and r.stdout.split()[1:] == ["1024", "2048"], (r.returncode, r.stdout, r.stderr[-500:])
+
+
 def test_planner_fuzz_under_sanitizers():
     """tests/cpp/test_planner_fuzz.cpp: random plans through plan_append / finalize (all kernel choices) / simulate with
     the planner compiled under AddressSanitizer + UBSan — the hint and sentinel scans index vectors by hand, and an
