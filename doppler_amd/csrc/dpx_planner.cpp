@@ -142,6 +142,8 @@ uint64_t lcm_u64(uint64_t a, uint64_t b)
 //   rows that do not start on a 128-byte line (L % 32 != 0): -20 % (a wavefront's 1 KiB piece then shares
 //     lines with wavefronts running on other XCDs);
 //   rows that are not a whole number of 4 KiB pages (L % 1024 != 0): about -3 %;
+//   rows shorter than 8192 samples or longer than 16384: -2 % / -3 % (the two rows of a wavefront are then 4-16 KiB
+//     or more than 128 KiB apart);
 //   idle lanes in the last 256-sample column slice: proportional.
 // At least 16 row groups must fit.  Returns 0 if no such L exists.
 uint32_t pick_row_length(uint32_t P, uint64_t body, uint32_t R)
@@ -161,6 +163,11 @@ uint32_t pick_row_length(uint32_t P, uint64_t body, uint32_t R)
             double score = (double)L / (256.0 * (double)((L + 255) / 256));
             if (L % 32 != 0) score -= 0.20;
             if (L % 1024 != 0) score -= 0.03;
+            // the row length itself (headline stream, all four format pairs, several boxes): 8192 samples is the best,
+            // 16384 within 1 %, 1024-4096 cost 1.5-3 %, 32768 and more 3-5 %
+            if (L < 8192) score -= 0.02;
+            else if (L > 16384) score -= 0.03;
+            else if (L > 8192) score -= 0.005;
             if (score > best_score + 1e-9) { best_score = score; best = (uint32_t)L; }
         }
     }
