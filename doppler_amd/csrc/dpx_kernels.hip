@@ -208,16 +208,19 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
                                                           const float2 *__restrict__ tab,   // table, origin = sample A
                                                           uint64_t A, uint32_t L, uint32_t cols,
                                                           uint64_t div_m, uint32_t div_s,
-                                                          uint32_t n_main, uint32_t P,
+                                                          uint32_t n_extra, uint32_t P,
                                                           // ---- ragged path only (not preloaded)
                                                           const DevSeg *__restrict__ segs,
                                                           RowsArgs ra)
 {
     constexpr int S = RowVec<IN_FMT, OUT_FMT>::S;
     constexpr int IB = Fmt<IN_FMT>::kBytes, OB = Fmt<OUT_FMT>::kBytes;
-    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x;
 
-    if (b < n_main) {
+    // the workgroups of the ragged ranges come first in the grid: their sincos work then overlaps the memory-bound
+    // matrix instead of forming a tail
+    if (blockIdx.x >= n_extra) {
+        const uint32_t b = blockIdx.x - n_extra;
         // (row group, column slice) = divmod(b, cols), exact magic-number division
         const uint32_t rg = (uint32_t)(((uint64_t)b * div_m) >> div_s);
         const uint32_t col = b - rg * cols;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
         // ragged ranges [r0, A) and [B, r1): 4 samples per lane, evaluated one by one
         const uint64_t head = ra.A - ra.r0;
         const uint64_t total = head + (ra.r1 - ra.B);
-        const uint64_t e0 = (uint64_t)(b - n_main) * (kRowsLanes * 4);
+        const uint64_t e0 = (uint64_t)blockIdx.x * (kRowsLanes * 4);
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {
             const uint64_t idx = e0 + (uint64_t)k * kRowsLanes + lane;
@@ -733,8 +736,8 @@ static int rows_t(const void *d_in, void *d_out, const DevSeg *d_segs, const voi
     const float2 *tab = lut + r.tab_off;
 #define DPX_ROWS_CASE(RR)                                                                                                                   \
     if (r.R == RR) {                                                                                                                        \
-        if (fma) rows_kernel<IN_FMT, OUT_FMT, true, RR><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_main, r.P, d_segs, r);  \
-        else     rows_kernel<IN_FMT, OUT_FMT, false, RR><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_main, r.P, d_segs, r); \
+        if (fma) rows_kernel<IN_FMT, OUT_FMT, true, RR><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_extra, r.P, d_segs, r);  \
+        else     rows_kernel<IN_FMT, OUT_FMT, false, RR><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_extra, r.P, d_segs, r); \
         return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                                                      \
     }
     DPX_ROWS_CASE(2) DPX_ROWS_CASE(4) DPX_ROWS_CASE(8)

@@ -125,7 +125,7 @@ uint32_t counter_at(const DevSeg &s, uint64_t j)
 namespace {
 
 constexpr uint64_t kRowsMinSamples = 1u << 16;   // below this a stretch stays on the tile kernel
-constexpr uint64_t kAbsorbMax = 4096;            // neighbouring crumbs a rows launch may evaluate itself
+constexpr uint64_t kAbsorbMax = 65536;           // neighbouring crumbs and tail a rows launch evaluates itself, sample by sample
 constexpr size_t kRowsMaxLaunches = 8;           // more tabulated stretches than this: one tile launch instead
 
 uint64_t lcm_u64(uint64_t a, uint64_t b)
