@@ -436,7 +436,8 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
     // instead of forming a tail
     if (blockIdx.x >= n_left_wg) {
         const uint32_t b = blockIdx.x - n_left_wg;
-        const uint32_t lane = tid & (kRowsLanes - 1), wave = tid / kRowsLanes;
+        // the wavefront index is uniform: telling the compiler so keeps all the row geometry below in scalar registers
+        const uint32_t lane = tid & (kRowsLanes - 1), wave = __builtin_amdgcn_readfirstlane(tid / kRowsLanes);
         uint32_t wi = whint[b >> kWalkHintShift];
         while (wsegs[wi + 1].wg_base <= b) ++wi;                  // the list ends with a sentinel
         const WalkSeg ws = wsegs[wi];
