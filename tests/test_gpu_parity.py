@@ -386,6 +386,45 @@ def test_walk_kernel_random_plans(ctx, orc):
     assert used_walk >= 5      # many of these plans really run on the walk kernel
 
 
+def test_kernels_stay_inside_the_output_buffer(ctx, orc):
+    """Guard bands of 64 KiB before and after the output stay untouched by every kernel choice (the walk kernel's
+    lanes without a sample store to a scratch area of the plan, the rows kernel pads its grid, tiles are masked)."""
+    import doppler_amd
+    guard = 65536
+    cases = [
+        ([(300000 + 13, 5000.0)], 1024000, 3),                                      # rows kernel + ragged head and tail
+        ([(50000 + 17 * k, 333.0 + k) for k in range(10)], 48000, 3),               # walk kernel, leftover ranges
+        ([(120001, 9876.543), (5000, 3.0), (70000, -1234.5)], 1024000, 4),          # tile kernel only
+        ([(3000000 + 77, 5001.0)], 1024000, 5),                                     # one long stretch forced onto the walk kernel
+    ]
+    for segs, rate, variant in cases:
+        for intype, outtype in (("i16", "i16"), ("f32", "i16"), ("i16", "f32")):
+            n = sum(c for c, _ in segs)
+            x = make_iq(intype, n, 77)
+            nb_out = n * BPS[outtype]
+            d_in, d_buf = ctx.malloc(max(16, x.size)), ctx.malloc(nb_out + 2 * guard)
+            try:
+                ctx.h2d(d_in, x)
+                fill = np.full(nb_out + 2 * guard, 0xC3, dtype=np.uint8)
+                ctx.h2d(d_buf, fill)
+                ctx.set_tuning(0, 0, variant)
+                try:
+                    plan = ctx.plan_segments(segs, rate)
+                    plan.run(d_in, intype, d_buf + guard, outtype)
+                    ctx.synchronize()
+                    plan.close()
+                finally:
+                    ctx.set_tuning(0, 0, 3)
+                back = np.empty_like(fill)
+                ctx.d2h(back, d_buf)
+                assert (back[:guard] == 0xC3).all() and (back[guard + nb_out:] == 0xC3).all(), (segs[:2], variant, intype, outtype)
+                want, _ = oracle_segments(orc, x, intype, outtype, segs, rate)
+                assert_same_bytes(back[guard:guard + nb_out], want, outtype, "guarded run variant %d" % variant)
+            finally:
+                ctx.free(d_in)
+                ctx.free(d_buf)
+
+
 def test_chunked_equals_whole(ctx, orc):
     """Time-chunk sharding: 5 block-aligned chunks seeded from the closed form reproduce
     the single-pass output byte for byte."""
