@@ -174,7 +174,7 @@ __device__ __forceinline__ uint32_t counter_at(const DevSeg &sg, uint64_t j)
 //     share one 32-byte table read per lane and need no phase arithmetic;
 //   * walk kernel (track mode, hundreds of stretches in one launch): same idea
 //     with rows shifted onto 128-byte lines and the 288 correctors of a column
-//     window shared by eight rows through LDS (the only LDS use in this file);
+//     window shared by ten rows through LDS (the only LDS use in this file);
 //   * tile kernel: whatever the two above leave.
 
 // ---- per-sample evaluation (ragged ranges and stretch boundaries)
@@ -394,8 +394,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
 
 
 // ---- walk kernel: many tabulated stretches in one launch (dpx_types.h, WalkSeg).
-// A workgroup = 4 wavefronts x 2 rows of ONE 256-sample column window: the window's correctors (288 table entries,
-// whatever the rows' shifts) are read from memory once, staged in LDS, and used by all eight rows.  One shot, no loop,
+// A workgroup = 5 wavefronts x 2 rows of ONE 256-sample column window: the window's correctors (288 table entries,
+// whatever the rows' shifts) are read from memory once, staged in LDS, and used by all ten rows.  One shot, no loop,
 // no divergent branch: the compiler serialises loads that sit in divergent blocks, so a lane without a sample
 // (past the end of its row, or a row past the end of the matrix) loads from the start of the matrix instead and
 // stores to a scratch area (`sink`).
@@ -584,8 +584,7 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
         if (P != 0) base = (uint32_t)(((uint64_t)(sg.n_start - 1u) + j0) % P);
         else        base = sg.n_start + (uint32_t)j0;
 #pragma unroll 1
-        for (uint32_t k = 0; k < kLeftBlock / THREADS; ++k) {
-            const uint32_t o = k * THREADS + tid;
+        for (uint32_t o = tid; o < kLeftBlock; o += THREADS) {
             if (o0 + o >= lr.len) break;
             uint32_t n;
             if (P == 0) {
@@ -772,7 +771,7 @@ static int walk_t(const void *d_in, void *d_out, const DevSeg *d_segs, const voi
         else     walk_kernel<IN_FMT, OUT_FMT, false, WW, UU, CC><<<grid, WW * 64, 0, st>>>(in, out, lut, d_walk, d_whint, w.n_left_wg, sink, d_left, d_lhint, d_segs); \
         return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                                                    \
     }
-    DPX_WALK_CASE(4, 2, true) DPX_WALK_CASE(4, 2, false) DPX_WALK_CASE(8, 2, true) DPX_WALK_CASE(8, 1, true) DPX_WALK_CASE(2, 2, true)
+    DPX_WALK_CASE(5, 2, false) DPX_WALK_CASE(5, 2, true) DPX_WALK_CASE(4, 2, false) DPX_WALK_CASE(6, 2, false) DPX_WALK_CASE(8, 2, false)
 #undef DPX_WALK_CASE
     return DPX_ERR_ARG;
 }

@@ -252,9 +252,9 @@ uint64_t walk_workgroups(const WalkSeg &w)
     return (uint64_t)((w.nw + 7) & ~7u) * walk_chunks(w);     // every chunk padded to a multiple of 8 workgroups
 }
 
-// stretches whose chunks are interleaved in dispatch order.  Measured (profiles/r01_secondary_workloads.md): interleaving
-// 8 stretches so that a stretch's next chunk starts ~4 us after the previous one does NOT make the table slices hit in
-// the L2 (FETCH_SIZE unchanged) and costs 10 % on short-period plans (less contiguous sweeps), so: 1.
+// stretches whose chunks are interleaved in dispatch order.  Measured (profiles/r01_secondary_workloads.md): the slices
+// of a stretch's later chunks are L2 hits already with the chunks adjacent (FETCH_SIZE = samples + the tables once);
+// interleaving 8 stretches changes nothing there and costs 10 % on short-period plans (less contiguous sweeps), so: 1.
 constexpr size_t kWalkGroup = 1;
 
 }  // namespace
@@ -397,7 +397,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
             if (w.E < end) pieces.push_back({w.E, end, (uint32_t)i});
             covered.push_back({w.A, w.E});
         }
-        // dispatch order: stretch by stretch, chunk by chunk, window fastest (a chunk sweeps its eight rows contiguously);
+        // dispatch order: stretch by stretch, chunk by chunk, window fastest (a chunk sweeps its ten rows contiguously);
         // every chunk is padded to a multiple of 8 workgroups so that window w of every chunk runs on XCD w % 8
         uint64_t wg = 0;
         const uint32_t rpw = walk_shape().waves * walk_shape().rows_per_wave;

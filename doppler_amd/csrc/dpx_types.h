@@ -78,13 +78,13 @@ struct RowsArgs {
 // ---- walk kernel: many tabulated periodic stretches in ONE launch (track mode: one stretch per second of stream).
 // A stretch [A, E) is viewed as rows of L samples (L a multiple of the period), row r starting at the 32-sample
 // boundary at or below A + r * L, so every wavefront access is a whole number of 128-byte lines whatever the
-// period.  A workgroup takes one 256-sample column window of eight consecutive rows (4 wavefronts x 2 rows): the
+// period.  A workgroup takes one 256-sample column window of ten consecutive rows (5 wavefronts x 2 rows): the
 // window's 288 correctors are fetched once from a plan-time table (or, as a measured alternative, evaluated by the
 // workgroup itself while its sample loads are in flight) and shared through LDS (the tile kernel reads 8 bytes of
 // table per sample, cold, because all tiles of a one-second stretch are in flight at once).  Row r is shifted left by
 // delta_r = (A + r * L) mod 32 samples, so its lanes index the table at kWalkPad - delta_r + column.
 // The launch is a list of row chunks (WalkSeg), stretch by stretch, each chunk padded to a multiple of 8 workgroups.
-struct WalkSeg {           // one row chunk (kWalkWaves x kWalkRowsPerWave rows) of one stretch's matrix
+struct WalkSeg {           // one row chunk (kWalkWaves x kWalkRowsPerWave = 10 rows) of one stretch's matrix
     uint64_t A;            // first sample of the matrix (multiple of 32)
     uint64_t E;            // one past its last sample (multiple of 32)
     uint32_t L;            // row length in samples
@@ -117,8 +117,8 @@ constexpr uint32_t kWalkMinL = 8192;       // shorter periods use a multiple as 
 constexpr int kWalkHintShift = 6;          // one WalkSeg hint per 64 workgroups
 constexpr int kLeftHintShift = 4;          // one LeftRange hint per 16 leftover workgroups
 constexpr uint32_t kLeftBlock = 1024;      // samples per leftover workgroup
-constexpr uint32_t kWalkWaves = 4;         // wavefronts per workgroup ...
-constexpr uint32_t kWalkRowsPerWave = 2;   // ... and rows per wavefront: 8 rows share one table slice
+constexpr uint32_t kWalkWaves = 5;         // wavefronts per workgroup ...
+constexpr uint32_t kWalkRowsPerWave = 2;   // ... and rows per wavefront: 10 rows share one table slice
 constexpr uint32_t kWalkSlice = kWalkWindow + kWalkPad;   // table entries a window needs: 288
 constexpr uint32_t kWalkSinkBytes = 512 * 16;             // where lanes without a sample store
 
