@@ -463,6 +463,11 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
         }
 
         const uint32_t r0 = ws.row0 + wave * U;
+        // a wavefront past the last row of the matrix has nothing to do; unless it produces part of the slice (the first
+        // kWalkSlice / 2 threads load it, or the first kWalkSlice threads evaluate it) it leaves at once — the barrier
+        // below only counts the wavefronts still alive
+        constexpr uint32_t kSliceThreads = COMPUTE ? kWalkSlice : kWalkSlice / 2;
+        if (r0 >= ws.rows && wave * kRowsLanes >= kSliceThreads) return;
         qvec qin[U][NV];
         uint32_t li[U][NV];                                       // index into the slice
         uint8_t *op[U][NV];
