@@ -438,9 +438,9 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
         const uint32_t b = blockIdx.x - n_left_wg;
         // the wavefront index is uniform: telling the compiler so keeps all the row geometry below in scalar registers
         const uint32_t lane = tid & (kRowsLanes - 1), wave = __builtin_amdgcn_readfirstlane(tid / kRowsLanes);
-        uint32_t wi = whint[b >> kWalkHintShift];
-        while (wsegs[wi + 1].wg_base <= b) ++wi;                  // the list ends with a sentinel
-        const WalkSeg ws = wsegs[wi];
+        // two dependent scalar loads before the first sample load: the chunk index (exact: chunks start on multiples of 8
+        // workgroups, one index per 8), then its descriptor
+        const WalkSeg ws = wsegs[whint[b >> kWalkHintShift]];
         const uint32_t w = b - ws.wg_base;
         if (w >= ws.nw) return;                                   // chunks are padded to a multiple of 8 workgroups
 

@@ -564,9 +564,8 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
         } else if (ln.kind == 2) {
             const WalkArgs &wa = ln.walk;
             for (uint32_t b = 0; b < wa.n_walk_wg; ++b) {
-                uint32_t wi = plan.walk_hint[b >> kWalkHintShift];
-                while (plan.walk[wi + 1].wg_base <= b) ++wi;
-                const WalkSeg &ws = plan.walk[wi];
+                const WalkSeg &ws = plan.walk[plan.walk_hint[b >> kWalkHintShift]];
+                if (b < ws.wg_base || b - ws.wg_base >= ((ws.nw + 7u) & ~7u)) { put(0, 0xfffffffcu); continue; }   // hint not exact
                 const TableBuild *tb = nullptr;
                 for (const TableBuild &t : plan.tables) if (t.off == ws.tab_off) tb = &t;
                 const uint32_t w = b - ws.wg_base;

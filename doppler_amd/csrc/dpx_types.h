@@ -114,7 +114,7 @@ static_assert(sizeof(LeftRange) == 24, "LeftRange is read with scalar loads");
 constexpr uint32_t kWalkPad = 32;          // table entries before column 0 (the largest row shift is 31)
 constexpr uint32_t kWalkWindow = 256;      // samples per column window
 constexpr uint32_t kWalkMinL = 8192;       // shorter periods use a multiple as the row length
-constexpr int kWalkHintShift = 6;          // one WalkSeg hint per 64 workgroups
+constexpr int kWalkHintShift = 3;          // one WalkSeg index per 8 workgroups: exact, every chunk is padded to a multiple of 8
 constexpr int kLeftHintShift = 4;          // one LeftRange hint per 16 leftover workgroups
 constexpr uint32_t kLeftBlock = 1024;      // samples per leftover workgroup
 constexpr uint32_t kWalkWaves = 5;         // wavefronts per workgroup ...
