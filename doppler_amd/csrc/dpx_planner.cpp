@@ -309,13 +309,31 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
         use_walk = in_matrices > 0 && in_matrices >= plan.n_samples / 2 && n_wg < 0x40000000ull;
     }
 
+    // Const-mode plans: a stretch whose period does not allow rows of whole 4 KiB pages (odd periods: the common case
+    // for an arbitrary integer --shift) runs 4-23 % faster as a walk-kernel matrix than as a rows launch with
+    // L = 32 P (measured, profiles/r01_secondary_workloads.md), and a stretch too short for a rows launch is better off
+    // there than on the tile kernel; page-aligned rows stay on the rows kernel.
+    std::vector<uint8_t> to_walk(ns, 0);
+    if (use_rows && choice == kChooseAuto) {
+        for (size_t i = 0; i < ns; ++i) {
+            uint64_t A;
+            uint32_t R, L;
+            WalkSeg w;
+            const bool page_rows = rows_geometry(plan.segs[i], &A, &R, &L) && L % 1024 == 0;
+            if (!page_rows && walk_geometry(plan.segs[i], &w)) {
+                to_walk[i] = 1;
+                plan.segs[i].flags |= kSegWalk;
+            }
+        }
+    }
+
     std::vector<Interval> covered;                   // what rows launches / walk matrices produce, in stream order
     std::vector<uint64_t> seg_covered_hi(ns, 0);     // per stretch: end of the part a rows launch covers (0 = none)
     for (size_t i = 0; use_rows && i < ns; ++i) {
         DevSeg &s = plan.segs[i];
         uint64_t A;
         uint32_t R, L;
-        if (!rows_geometry(s, &A, &R, &L)) continue;
+        if (to_walk[i] || !rows_geometry(s, &A, &R, &L)) continue;
         const uint64_t end = s.first + s.count;
         const uint64_t n_rg = (end - A) / ((uint64_t)R * L);
         s.flags |= kSegRows;
@@ -348,7 +366,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
         uint32_t lo = own;
         while (lo > 0) {
             const DevSeg &p = plan.segs[lo - 1];
-            if ((p.flags & kSegRows) || p.first < covered_hi || ln.rows.A - p.first > kAbsorbMax) break;
+            if ((p.flags & (kSegRows | kSegWalk)) || p.first < covered_hi || ln.rows.A - p.first > kAbsorbMax) break;
             --lo;
         }
         ln.rows.seg_lo = lo;
@@ -358,7 +376,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
             uint32_t hi = own + 1;
             while (hi < ns) {
                 const DevSeg &q = plan.segs[hi];
-                if ((q.flags & kSegRows) || q.first + q.count - ln.rows.B > kAbsorbMax) break;
+                if ((q.flags & (kSegRows | kSegWalk)) || q.first + q.count - ln.rows.B > kAbsorbMax) break;
                 ln.rows.r1 = q.first + q.count;
                 ++hi;
             }
@@ -371,14 +389,29 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
     // ---- walk matrices, and the pieces of the stream they leave out
     struct Piece { uint64_t lo, hi; uint32_t seg; };
     std::vector<Piece> pieces;
-    if (use_walk) {
-        std::vector<WalkSeg> mats;                   // one per qualifying stretch, in stream order
+    bool any_to_walk = false;
+    for (size_t i = 0; i < ns; ++i) any_to_walk = any_to_walk || to_walk[i];
+    if (use_walk || any_to_walk) {
+        std::vector<WalkSeg> mats;                   // one per stretch that becomes a matrix, in stream order
+        const std::vector<Interval> rows_cov = covered;        // rows launches, disjoint, in stream order
+        size_t rc = 0;
+        // the parts of [lo, hi) that no rows launch produces
+        auto uncovered = [&](uint64_t lo, uint64_t hi, uint32_t seg) {
+            while (rc < rows_cov.size() && rows_cov[rc].hi <= lo) ++rc;
+            uint64_t pos2 = lo;
+            for (size_t k = rc; k < rows_cov.size() && rows_cov[k].lo < hi; ++k) {
+                if (rows_cov[k].lo > pos2) pieces.push_back({pos2, rows_cov[k].lo, seg});
+                pos2 = std::max(pos2, rows_cov[k].hi);
+            }
+            if (pos2 < hi) pieces.push_back({pos2, hi, seg});
+        };
         for (size_t i = 0; i < ns; ++i) {
             DevSeg &s = plan.segs[i];
             const uint64_t end = s.first + s.count;
             WalkSeg w;
-            if (!walk_geometry(s, &w)) {
-                pieces.push_back({s.first, end, (uint32_t)i});
+            if (!(use_walk || to_walk[i]) || !walk_geometry(s, &w)) {
+                s.flags &= ~kSegWalk;
+                uncovered(s.first, end, (uint32_t)i);
                 continue;
             }
             s.flags |= kSegWalk;
@@ -393,8 +426,8 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
                 pool += ((uint64_t)n_entries + 3) & ~3ull;
             }
             mats.push_back(w);
-            if (s.first < w.A) pieces.push_back({s.first, w.A, (uint32_t)i});
-            if (w.E < end) pieces.push_back({w.E, end, (uint32_t)i});
+            if (s.first < w.A) uncovered(s.first, w.A, (uint32_t)i);
+            if (w.E < end) uncovered(w.E, end, (uint32_t)i);
             covered.push_back({w.A, w.E});
         }
         // dispatch order: stretch by stretch, chunk by chunk, window fastest (a chunk sweeps its ten rows contiguously);
