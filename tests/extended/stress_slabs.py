@@ -1,5 +1,6 @@
-"""Stress: the track-replay stream of tests/test_gpu_cli.py cut into slabs at random block boundaries (what pipe timing
-does to the `doppler` command), every cut pattern through the dpx_stream_* ring, compared with the oracle."""
+"""Stress: the track-replay stream of tests/test_gpu_cli.py (or, with a third argument N, `const --shift N`) cut into
+slabs at random block boundaries (what pipe timing does to the `doppler` command), every cut pattern through the
+dpx_stream_* ring, compared with the oracle.  python tests/extended/stress_slabs.py <seed> <trials> [shift]"""
 import sys
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +14,12 @@ rate, freq, off = 256000, 437505000, -2500
 rr = 6.8 * np.tanh((np.arange(16) - 6.0) / 2.0)
 n = rate * 9 + 2048 * 2 + 55
 x = make_iq("i16", n, 5)
-want, _, log = orc.track_stream(x, "i16", "i16", rate, freq, rr, offset_hz=off)
+const_shift = int(sys.argv[3]) if len(sys.argv) > 3 else None     # third argument: `doppler const --shift N` instead of track
+if const_shift is None:
+    want, _, log = orc.track_stream(x, "i16", "i16", rate, freq, rr, offset_hz=off)
+else:
+    want, _ = orc.const_stream(x, "i16", "i16", const_shift, rate)
+    log = [float(const_shift)] * ((x.size + 8191) // 8192)
 want = np.asarray(want)
 spb = 2048
 nblocks = (x.size + 8191) // 8192
