@@ -318,3 +318,85 @@ long orc_const_stream_mt(const uint8_t *in, size_t in_len, int intype, int outty
     }
     return total;
 }
+
+/* ------------------------------------------- checker for sharded streams -- */
+/* A stream of piecewise-constant shifts (what the per-block loop of main.rs:156-184 produces once equal
+ * neighbouring blocks are merged; one segment for main.rs:102-119), starting from a counter the caller carries.
+ * The counter at every thread's first sample comes from the sequential rule (dsp.rs:125-130) run over all the
+ * preceding samples of this call — no closed form is assumed anywhere in the oracle.  Threads then run the
+ * reference's three passes (A1/A2 -> A3/A4 -> A5/A6) over pieces of at most one reference block. */
+typedef struct {
+    const uint8_t *in; uint8_t *out; int intype, outtype; uint32_t samplerate;
+    const orc_segment *segs; size_t n_segs;
+    uint64_t lo, hi;            /* sample range of this thread */
+    size_t seg0; uint64_t seg0_first;   /* segment holding `lo`, and its first sample */
+    uint32_t samplenum;         /* counter at `lo` */
+} seg_job;
+
+static void *seg_worker(void *arg)
+{
+    seg_job *j = (seg_job *)arg;
+    const size_t ib = bps(j->intype), ob = bps(j->outtype);
+    orc_complex a[2048], b[2048];
+    size_t si = j->seg0;
+    uint64_t first = j->seg0_first, pos = j->lo;
+    uint32_t sn = j->samplenum;
+    while (pos < j->hi) {
+        while (pos >= first + j->segs[si].n_samples) { first += j->segs[si].n_samples; si++; }
+        uint64_t end = first + j->segs[si].n_samples;
+        if (end > j->hi) end = j->hi;
+        size_t n = (size_t)(end - pos < 2048 / (ib / 4) ? end - pos : 2048 / (ib / 4));
+        if (j->intype == ORC_FMT_I16) orc_convert_iqi16_to_complex(j->in + pos * ib, n * ib, a);
+        else orc_convert_iqf32_to_complex(j->in + pos * ib, n * ib, a);
+        orc_shift_frequency(a, n, &sn, j->segs[si].shift_hz, j->samplerate, b);
+        if (j->outtype == ORC_FMT_I16) orc_pack_i16(b, n, j->out + pos * ob);
+        else orc_pack_f32(b, n, j->out + pos * ob);
+        pos += n;
+    }
+    return NULL;
+}
+
+long orc_segments_stream_mt(const uint8_t *in, int intype, int outtype, uint32_t samplerate,
+                            const orc_segment *segs, size_t n_segs, uint32_t *samplenum,
+                            uint8_t *out, int n_threads)
+{
+    if ((intype != ORC_FMT_I16 && intype != ORC_FMT_F32) || (outtype != ORC_FMT_I16 && outtype != ORC_FMT_F32))
+        return ORC_ERR_ARG;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_segs; ++i) total += segs[i].n_samples;
+    if (total == 0) return 0;
+    const uint64_t per = (total + (uint64_t)n_threads - 1) / (uint64_t)n_threads;
+    pthread_t th[256];
+    seg_job jobs[256];
+    int used = 0;
+    /* one sequential pass of the counter rule over the whole call; thread starts are noted on the way */
+    uint32_t sn = *samplenum;
+    size_t si = 0;
+    uint64_t first = 0, pos = 0;
+    while (pos < total) {
+        while (pos >= first + segs[si].n_samples) { first += segs[si].n_samples; si++; }
+        seg_job *j = &jobs[used];
+        j->in = in; j->out = out; j->intype = intype; j->outtype = outtype; j->samplerate = samplerate;
+        j->segs = segs; j->n_segs = n_segs;
+        j->lo = pos; j->hi = pos + per < total ? pos + per : total;
+        j->seg0 = si; j->seg0_first = first; j->samplenum = sn;
+        used++;
+        uint64_t p = pos;
+        size_t s2 = si;
+        uint64_t f2 = first;
+        while (p < j->hi) {
+            while (p >= f2 + segs[s2].n_samples) { f2 += segs[s2].n_samples; s2++; }
+            uint64_t end = f2 + segs[s2].n_samples;
+            if (end > j->hi) end = j->hi;
+            orc_advance_samplenum(&sn, segs[s2].shift_hz, samplerate, end - p);
+            p = end;
+        }
+        pos = j->hi;
+    }
+    for (int t = 0; t < used; ++t) pthread_create(&th[t], NULL, seg_worker, &jobs[t]);
+    for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
+    *samplenum = sn;
+    return (long)(total * bps(outtype));
+}

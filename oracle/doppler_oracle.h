@@ -107,6 +107,15 @@ long orc_track_stream(const uint8_t *in, size_t in_len, int intype, int outtype,
 long orc_const_stream_mt(const uint8_t *in, size_t in_len, int intype, int outtype,
                          int32_t shift, uint32_t samplerate, uint8_t *out, int n_threads);
 
+/* ---- checker for sharded / piecewise-constant streams --------------------- */
+/* `segs`: runs of samples with one f32 shift each (main.rs:110 / main.rs:177 after merging equal
+ * neighbouring blocks).  *samplenum is the carried counter (in/out); the counter at every thread's first
+ * sample is obtained with the sequential rule, never a closed form.  Returns bytes written. */
+typedef struct { uint64_t n_samples; float shift_hz; } orc_segment;
+long orc_segments_stream_mt(const uint8_t *in, int intype, int outtype, uint32_t samplerate,
+                            const orc_segment *segs, size_t n_segs, uint32_t *samplenum,
+                            uint8_t *out, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,9 @@ def _load():
     lib.orc_const_stream_mt.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int32, C.c_uint32,
                                         C.c_void_p, C.c_int]
     lib.orc_const_stream_mt.restype = C.c_long
+    lib.orc_segments_stream_mt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, u32p,
+                                           C.c_void_p, C.c_int]
+    lib.orc_segments_stream_mt.restype = C.c_long
     lib.orc_track_stream.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                                      C.c_int32, C.c_int, C.c_void_p, C.c_size_t, u32p, C.c_void_p,
                                      C.c_void_p, C.POINTER(C.c_size_t)]
@@ -212,6 +215,31 @@ def const_stream(inbytes, intype, outtype, shift, samplerate, samplenum=0, threa
     if r < 0:
         raise OracleError("reference would panic (trailing partial sample), code %d" % r)
     return out[:r], sn_val
+
+
+class _Segment(C.Structure):
+    _fields_ = [("n_samples", C.c_uint64), ("shift_hz", C.c_float)]
+
+
+def segments_stream(inbytes, intype, outtype, segments, samplerate, samplenum=0, threads=1, out=None):
+    """A stream of (n_samples, shift_hz) runs, counter carried in from `samplenum` and on through every run with the
+    sequential rule of dsp.rs:125-130 (also to find each thread's starting counter).  Returns (out_bytes, samplenum)."""
+    b = _bytes(inbytes)
+    it, ot = _FMT[intype], _FMT[outtype]
+    segs = [(int(n), float(hz)) for n, hz in segments if n]
+    total = sum(n for n, _ in segs)
+    assert b.size == total * _BPS[it], (b.size, total)
+    arr = (_Segment * max(1, len(segs)))()
+    for i, (n, hz) in enumerate(segs):
+        arr[i].n_samples, arr[i].shift_hz = n, hz
+    if out is None:
+        out = np.empty(total * _BPS[ot] + 8, dtype=np.uint8)
+    sn = C.c_uint32(samplenum)
+    r = lib.orc_segments_stream_mt(b.ctypes.data, it, ot, samplerate, arr, len(segs), C.byref(sn), out.ctypes.data,
+                                   int(threads))
+    if r < 0:
+        raise OracleError("bad arguments, code %d" % r)
+    return out[:r], sn.value
 
 
 def track_stream(inbytes, intype, outtype, samplerate, frequency_hz, range_rate_km_s, offset_hz=None,

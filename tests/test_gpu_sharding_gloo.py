@@ -1,0 +1,123 @@
+"""GPU, real processes: the multi-rank path with every rank calling the HIP kernel (the -m "not gpu" twin,
+tests/test_sharding_gloo.py, has the oracle standing in for the kernel).
+
+A test box has one GPU, so the ranks share device 0 and talk over gloo (RCCL refuses two ranks on one device); what is
+exercised is everything above the transport: block-aligned time chunks, closed-form seeds (const) and per-segment seeds
+(track), the kernel at a rank offset, per-rank D2H, the ordered gather, and bench.py's own multi-rank code path.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BPS = {"i16": 4, "f32": 8}
+
+
+def _stream(intype, n, seed):
+    rng = np.random.default_rng(seed)
+    if intype == "i16":
+        return rng.integers(-32768, 32768, size=2 * n, dtype=np.int16).view(np.uint8)
+    return rng.uniform(-1, 1, size=2 * n).astype(np.float32).view(np.uint8)
+
+
+def _cases():
+    rate = 1024000
+    track = [((rate // 1024 + 3 * (k % 5)) * 1024, float(np.float32(4000.0 - 37.25 * k))) for k in range(24)]
+    track[-1] = (track[-1][0] + 77, track[-1][1])
+    return [
+        ("const 5001 Hz i16->i16 (odd period, seeds mid-period)", "i16", "i16", [(2048 * 4100 + 333, 5001.0)], rate),
+        ("const 815 kHz f32->f32", "f32", "f32", [(1024 * 3001 + 5, 815000.0)], 2400000),
+        ("track-shaped, 24 shifts, f32->i16", "f32", "i16", track, rate),
+    ]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import doppler_amd
+    from doppler_amd import shard
+    ctx = doppler_amd.Context(0)                       # every rank on the one GPU of the box
+    dev = torch.device("cuda", 0)
+    results = []
+    for ci, (name, intype, outtype, segs, rate) in enumerate(_cases()):
+        n = sum(c for c, _ in segs)
+        x = _stream(intype, n, 500 + ci)               # same stream on every rank
+        lo, hi = shard.chunk_bounds(n, world, rank, bytes_per_sample=BPS[intype])
+        before, inside = shard.segments_for_chunk(segs, lo, hi)
+        seed = shard.seed_for_segments(before, rate)
+        if len(segs) == 1:
+            assert seed == shard.chunk_seed(segs[0][1], rate, lo)
+        xd = torch.from_numpy(x[lo * BPS[intype]:hi * BPS[intype]].copy()).to(dev)
+        out = torch.empty((hi - lo) * BPS[outtype], dtype=torch.uint8, device=dev)
+        plan = ctx.plan_segments(inside, rate, samplenum=seed)
+        plan.run_tensors(xd, out, intype, outtype)
+        torch.cuda.synchronize(dev)
+        plan.close()
+        sizes = []
+        for r in range(world):
+            a, b = shard.chunk_bounds(n, world, r, bytes_per_sample=BPS[intype])
+            sizes.append((b - a) * BPS[outtype])
+        full = shard.ordered_gather(out.cpu(), sizes, dst=0)          # per-rank D2H, then ordered point-to-point gather
+        if rank == 0:
+            from oracle import oracle as orc
+            want, _ = orc.segments_stream(x, intype, outtype, segs, rate, threads=min(os.cpu_count() or 1, 32))
+            got = full.numpy()
+            if outtype == "f32":
+                g, w = got.view(np.float32), want.view(np.float32)
+                ok = bool(np.all((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(g) & np.isnan(w))))
+            else:
+                ok = bool(np.array_equal(got, want))
+            results.append((name, ok))
+        else:
+            assert full is None
+    if rank == 0:
+        q.put(results)
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_call_the_kernel_then_ordered_gather(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(results) == len(_cases())
+    for name, ok in results:
+        assert ok, name
+
+
+def test_bench_multi_rank_code_path_on_a_shared_gpu():
+    """bench.py --gpus 2 exactly as the driver launches it, except that both ranks share GPU 0 over gloo
+    (DPX_BENCH_SHARE_GPU=1): chunk seeds, barrier + max-over-ranks timing, the gather leg, one JSON line from rank 0.
+    The numbers of such a run mean nothing and are not asserted."""
+    env = dict(os.environ, DPX_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29700 + (os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["config"]["samples_per_gpu"] == 268435456
+    assert "roofline" in line and "gather" in line

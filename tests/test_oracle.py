@@ -146,3 +146,30 @@ def test_oracle_edge_cases(orc):
     x = np.array([32767, -32768, 1000, -1], dtype=np.int16).view(np.uint8)
     y, sn = orc.const_stream(x, "i16", "i16", 0, 1024000)
     assert sn == 1 and y.view(np.int16).tolist() == [32766, -32767, 999, 0]
+
+
+def test_segments_stream_checker_equals_the_block_loop(orc):
+    """oracle.segments_stream (the multi-threaded checker for sharded streams) against the block-by-block restatements
+    it stands in for: the golden track replay (per-block shifts of main.rs:156-184), and `doppler const` with a carried
+    counter, for several thread counts and starting counters."""
+    t = load_golden("track_stream_case.npz")
+    rate, _, _, sn = t["meta"]
+    x = t["x"]
+    n = x.size // 4
+    segs = [(min(2048, n - b * 2048), float(hz)) for b, hz in enumerate(t["shift_log"]) if n - b * 2048 > 0]
+    for threads in (1, 3, 8):
+        got, fin = orc.segments_stream(x, "i16", "i16", segs, int(rate), threads=threads)
+        assert fin == int(sn)
+        assert_same_bytes(got, t["y"], "i16", "segments_stream vs golden track stream, %d threads" % threads)
+    rng = np.random.default_rng(5)
+    for intype, outtype in (("i16", "f32"), ("f32", "i16")):
+        m = 2048 * 37 + 99
+        xb = (rng.integers(-32768, 32768, size=2 * m, dtype=np.int16).view(np.uint8) if intype == "i16"
+              else rng.uniform(-1, 1, size=2 * m).astype(np.float32).view(np.uint8))
+        for sn0 in (0, 1, 2591, 77777):
+            want, sn_w = orc.const_stream(xb, intype, outtype, 9876, 1024000, samplenum=sn0)
+            got, sn_g = orc.segments_stream(xb, intype, outtype, [(m, 9876.0)], 1024000, samplenum=sn0, threads=5)
+            assert sn_g == sn_w
+            assert_same_bytes(got, want, outtype, "segments_stream vs const_stream sn0=%d" % sn0)
+    out, fin = orc.segments_stream(np.zeros(0, np.uint8), "i16", "i16", [], 1000, samplenum=7, threads=4)
+    assert out.size == 0 and fin == 7
