@@ -19,7 +19,7 @@ lib: $(LIB)
 
 # -amdgpu-kernarg-preload-count=16: the first 16 dwords of kernel arguments arrive in SGPRs,
 # so the one-shot wavefronts issue their loads without an s_load round trip (see rows_kernel).
-$(LIBDIR)/dpx_kernels.o: $(CSRC)/dpx_kernels.hip $(CSRC)/dpx_sincos.cuh $(CSRC)/dpx_types.h include/doppler_hip.h
+$(LIBDIR)/dpx_kernels.o: $(CSRC)/dpx_kernels.hip $(CSRC)/dpx_sincos.h $(CSRC)/dpx_types.h include/doppler_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -mllvm -amdgpu-kernarg-preload-count=16 -c $< -o $@
 

@@ -34,6 +34,24 @@ class Layout(C.Structure):
                 ("leftover_ranges", C.c_uint32), ("leftover_workgroups", C.c_uint32)]
 
 
+class Options(C.Structure):
+    _fields_ = [("rows_mult", C.c_uint32), ("rows_maxl", C.c_uint32), ("rows_r", C.c_uint32), ("walk_waves", C.c_uint32),
+                ("walk_rows", C.c_uint32), ("walk_compute", C.c_int32), ("walk_table_rows", C.c_uint32), ("reserved", C.c_uint32),
+                ("walk_tilemin", C.c_uint64)]
+
+
+def make_options(opts):
+    """None or a dict of dpx_options fields -> pointer argument (None = defaults)."""
+    if not opts:
+        return None
+    o = Options(walk_compute=-1)
+    for k, v in opts.items():
+        if k not in dict(Options._fields_):
+            raise KeyError("unknown option %r" % k)
+        setattr(o, k, int(v))
+    return C.byref(o)
+
+
 def declared_symbols():
     """Every function include/doppler_hip.h declares (parsed from the header text)."""
     with open(HEADER_PATH) as f:
@@ -61,8 +79,9 @@ _SIGNATURES = {
     "dpx_find_reset": (_i, [_f, _u32, _u32, _u64, _P(_u32), _P(_i)]),
     "dpx_samplenum_after": (_i, [_f, _u32, _u32, _u64, _P(_u32)]),
     "dpx_plan_describe": (_i, [_P(Segment), _sz, _u32, _u32, _i, _P(Stretch), _sz, _P(_sz), _P(_u32)]),
-    "dpx_plan_simulate": (_i, [_P(Segment), _sz, _u32, _u32, _i, _i, _i, _vp, _vp, _u64]),
-    "dpx_plan_layout": (_i, [_P(Segment), _sz, _u32, _u32, _i, _i, _i, _P(Layout)]),
+    "dpx_plan_simulate": (_i, [_P(Segment), _sz, _u32, _u32, _i, _i, _i, _vp, _vp, _vp, _u64]),
+    "dpx_plan_layout": (_i, [_P(Segment), _sz, _u32, _u32, _i, _i, _i, _vp, _P(Layout)]),
+    "dpx_set_options": (_i, [_vp, _vp]),
     "dpx_track_schedule": (_i, [_vp, _sz, _u32, _u32, C.c_int32, _i, _i, _u64, _vp, _sz, _P(_sz)]),
     "dpx_orbit_observe": (_i, [C.c_char_p, C.c_char_p, C.c_double, C.c_double, C.c_double, C.c_double, _vp]),
     "dpx_orbit_propagate": (_i, [C.c_char_p, C.c_char_p, C.c_double, _vp]),

@@ -52,6 +52,7 @@ struct dpx_ctx {
     int vecs = 2;             // tile kernel: 4-sample groups per lane (1 or 2); 128 x 2 measured best
     int variant = 0;
     int choice = dpx::kChooseAuto;   // which kernels finalize() may use (dpx_set_tuning)
+    dpx::PlanTuning tuning;          // kernel-shape knobs (dpx_set_options)
     hipStream_t stream = nullptr;   // internal stream of the host-pointer entry points
     void *stage_in = nullptr;
     void *stage_out = nullptr;
@@ -69,8 +70,7 @@ struct DevPlan {
     size_t cap = 0;
     dpx::DevSeg *segs = nullptr;
     uint32_t *hint = nullptr;
-    dpx::WalkSeg *walk = nullptr;
-    uint32_t *walk_hint = nullptr;
+    dpx::WalkSeg *walk = nullptr;   // one descriptor per 2^kWalkHintShift workgroups of the walk launch
     dpx::LeftRange *left = nullptr;
     uint32_t *left_hint = nullptr;
     void *sink = nullptr;          // where walk-kernel lanes without a sample store
@@ -124,6 +124,21 @@ inline int choice_of(int variant)
                                                                                                  : dpx::kChooseAuto;
 }
 
+dpx::PlanTuning tuning_of(const dpx_options *o)
+{
+    dpx::PlanTuning t;
+    if (!o) return t;
+    t.rows_mult = o->rows_mult;
+    t.rows_maxl = o->rows_maxl;
+    t.rows_r = o->rows_r;
+    t.walk_waves = o->walk_waves;
+    t.walk_rows = o->walk_rows;
+    t.walk_compute = o->walk_compute;
+    t.walk_table_rows = o->walk_table_rows;
+    t.walk_tilemin = o->walk_tilemin;
+    return t;
+}
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // Upload stretch + hint tables and fill the corrector tables (async on `st`).
@@ -132,13 +147,13 @@ int materialize(dpx_ctx *ctx, const dpx::PlanResult &plan, DevPlan &dev, bool fm
 {
     const size_t seg_bytes = align256(plan.segs.size() * sizeof(dpx::DevSeg));
     const size_t hint_bytes = align256(plan.hint.size() * sizeof(uint32_t));
-    const size_t walk_bytes = align256(plan.walk.size() * sizeof(dpx::WalkSeg));
-    const size_t whint_bytes = align256(plan.walk_hint.size() * sizeof(uint32_t));
+    const size_t n_wdesc = plan.walk.empty() ? 0 : plan.walk_hint.size();
+    const size_t walk_bytes = align256(n_wdesc * sizeof(dpx::WalkSeg));
     const size_t left_bytes = align256(plan.left.size() * sizeof(dpx::LeftRange));
     const size_t lhint_bytes = align256(plan.left_hint.size() * sizeof(uint32_t));
     const size_t lut_bytes = align256(plan.lut_entries * 8 + 64);
     const size_t sink_bytes = align256(dpx::kWalkSinkBytes);
-    const size_t need = seg_bytes + hint_bytes + walk_bytes + whint_bytes + left_bytes + lhint_bytes + sink_bytes + lut_bytes;
+    const size_t need = seg_bytes + hint_bytes + walk_bytes + left_bytes + lhint_bytes + sink_bytes + lut_bytes;
     if (need > dev.cap) {
         if (dev.buf) {
             DPX_HIP(hipStreamSynchronize(st));
@@ -155,21 +170,21 @@ int materialize(dpx_ctx *ctx, const dpx::PlanResult &plan, DevPlan &dev, bool fm
     dev.hint = reinterpret_cast<uint32_t *>(base + seg_bytes);
     char *p = base + seg_bytes + hint_bytes;
     dev.walk = reinterpret_cast<dpx::WalkSeg *>(p);          p += walk_bytes;
-    dev.walk_hint = reinterpret_cast<uint32_t *>(p);         p += whint_bytes;
     dev.left = reinterpret_cast<dpx::LeftRange *>(p);        p += left_bytes;
     dev.left_hint = reinterpret_cast<uint32_t *>(p);         p += lhint_bytes;
     dev.sink = p;                                            p += sink_bytes;
     dev.lut = p;
     // one host image of all the small tables, one copy (every hipMemcpyAsync from pageable memory costs 5-8 us)
-    const size_t image_bytes = seg_bytes + hint_bytes + walk_bytes + whint_bytes + left_bytes + lhint_bytes;
+    const size_t image_bytes = seg_bytes + hint_bytes + walk_bytes + left_bytes + lhint_bytes;
     dev.image.assign(image_bytes, 0);
     char *img = dev.image.data();
     auto put = [&](size_t off, const void *src, size_t bytes) { if (bytes) memcpy(img + off, src, bytes); };
     size_t off = 0;
     put(off, plan.segs.data(), plan.segs.size() * sizeof(dpx::DevSeg));              off += seg_bytes;
     put(off, plan.hint.data(), plan.hint.size() * sizeof(uint32_t));                 off += hint_bytes;
-    put(off, plan.walk.data(), plan.walk.size() * sizeof(dpx::WalkSeg));             off += walk_bytes;
-    put(off, plan.walk_hint.data(), plan.walk_hint.size() * sizeof(uint32_t));       off += whint_bytes;
+    // the chunk descriptor of every group of 8 workgroups, so that a workgroup finds its own with one scalar load
+    for (size_t h = 0; h < n_wdesc; ++h) memcpy(img + off + h * sizeof(dpx::WalkSeg), &plan.walk[plan.walk_hint[h]], sizeof(dpx::WalkSeg));
+    off += walk_bytes;
     put(off, plan.left.data(), plan.left.size() * sizeof(dpx::LeftRange));           off += left_bytes;
     put(off, plan.left_hint.data(), plan.left_hint.size() * sizeof(uint32_t));
     DPX_HIP(hipMemcpyAsync(base, img, image_bytes, hipMemcpyHostToDevice, st));
@@ -190,7 +205,7 @@ int run_plan(const dpx::PlanResult &plan, const DevPlan &dev, const void *d_in, 
         if (ln.kind == 0)
             rc = dpx::launch_rows(d_in, in_fmt, d_out, out_fmt, dev.segs, dev.lut, ln.rows, fma, st);
         else if (ln.kind == 2)
-            rc = dpx::launch_walk(d_in, in_fmt, d_out, out_fmt, dev.segs, dev.lut, dev.walk, dev.walk_hint, dev.left,
+            rc = dpx::launch_walk(d_in, in_fmt, d_out, out_fmt, dev.segs, dev.lut, dev.walk, dev.left,
                                   dev.left_hint, dev.sink, ln.walk, fma, st);
         else
             rc = dpx::launch_tiles(d_in, in_fmt, d_out, out_fmt, dev.segs, (uint32_t)plan.segs.size(), dev.hint,
@@ -270,7 +285,7 @@ int run_host(dpx_ctx *ctx, const void *in, size_t n, int in_fmt, void *out, int 
         return DPX_OK;
     }
     const dpx::LaunchGeom g = geometry(ctx);
-    dpx::finalize(plan, g.tile(), ctx->choice);
+    dpx::finalize(plan, g.tile(), ctx->choice, ctx->tuning);
     if (plan.error) return fail(DPX_ERR_PLAN, "%s", plan.error);
     const size_t in_bytes = n * bytes_per_sample(in_fmt), out_bytes = n * bytes_per_sample(out_fmt);
     int rc = ensure_stage(ctx, in_bytes, out_bytes);
@@ -364,6 +379,19 @@ int dpx_set_tuning(dpx_ctx *ctx, int block, int vecs, int variant)
     if (vecs) ctx->vecs = vecs;
     ctx->choice = choice_of(variant);
     ctx->variant = variant >= 3 ? 0 : variant;
+    return DPX_OK;
+}
+
+int dpx_set_options(dpx_ctx *ctx, const dpx_options *opt)
+{
+    if (!ctx) return fail(DPX_ERR_ARG, "ctx is null");
+    if (opt) {
+        if (opt->rows_r != 0 && opt->rows_r != 2 && opt->rows_r != 4 && opt->rows_r != 8) return fail(DPX_ERR_ARG, "rows_r must be 2, 4 or 8");
+        const uint32_t ww = opt->walk_waves;
+        if (ww != 0 && ww != 4 && ww != 5 && ww != 6 && ww != 8) return fail(DPX_ERR_ARG, "walk_waves must be 4, 5, 6 or 8");
+        if (opt->walk_rows > 4) return fail(DPX_ERR_ARG, "walk_rows must be 1..4");
+    }
+    ctx->tuning = tuning_of(opt);
     return DPX_OK;
 }
 
@@ -520,7 +548,7 @@ int dpx_plan_describe(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
 }
 
 int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
-                      uint32_t samplenum0, int block, int vecs, int variant,
+                      uint32_t samplenum0, int block, int vecs, int variant, const dpx_options *opt,
                       uint32_t *counters, uint8_t *writes, uint64_t n_samples)
 {
     if ((n_segs && !segs) || !counters || !writes) return fail(DPX_ERR_ARG, "bad argument");
@@ -534,14 +562,14 @@ int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
     dpx::LaunchGeom g;
     g.block = block ? block : 128;
     g.vecs = vecs ? vecs : 2;
-    dpx::finalize(plan, g.tile(), choice_of(variant));
+    dpx::finalize(plan, g.tile(), choice_of(variant), tuning_of(opt));
     memset(writes, 0, n_samples);
     dpx::simulate(plan, counters, writes);
     return DPX_OK;
 }
 
 int dpx_plan_layout(const dpx_segment *segs, size_t n_segs, uint32_t samplerate, uint32_t samplenum0,
-                    int block, int vecs, int variant, dpx_layout *out)
+                    int block, int vecs, int variant, const dpx_options *opt, dpx_layout *out)
 {
     if ((n_segs && !segs) || !out) return fail(DPX_ERR_ARG, "bad argument");
     dpx::PlanResult plan;
@@ -552,7 +580,7 @@ int dpx_plan_layout(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
     dpx::LaunchGeom g;
     g.block = block ? block : 128;
     g.vecs = vecs ? vecs : 2;
-    dpx::finalize(plan, g.tile(), choice_of(variant));
+    dpx::finalize(plan, g.tile(), choice_of(variant), tuning_of(opt));
     if (plan.error) return fail(DPX_ERR_PLAN, "%s", plan.error);
     memset(out, 0, sizeof *out);
     out->n_samples = plan.n_samples;
@@ -568,13 +596,14 @@ int dpx_plan_layout(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
             out->tile_samples += ln.tiles.m1 - ln.tiles.m0;
         } else {
             ++out->walk_launches;
-            out->walk_workgroups = ln.walk.n_walk_wg;
             out->leftover_workgroups = ln.walk.n_left_wg;
         }
     }
     if (!plan.walk.empty()) {
         out->leftover_ranges = (uint32_t)plan.left.size() - 1;
         for (size_t i = 0; i + 1 < plan.walk.size(); ++i) {
+            if (plan.walk[i].upw == 0) continue;                  // a group of leftover blocks
+            out->walk_workgroups += (plan.walk[i].nw + 7u) & ~7u; // chunks are padded to multiples of 8 workgroups
             if (plan.walk[i].row0 != 0) continue;                 // one descriptor per row chunk: count matrices once
             ++out->walk_matrices;
             out->walk_samples += plan.walk[i].E - plan.walk[i].A;
@@ -663,7 +692,7 @@ int dpx_plan_segments(dpx_ctx *ctx, const dpx_segment *segs, size_t n_segs, uint
     for (size_t i = 0; i < n_segs; ++i)
         dpx::plan_append(p->host, dpx::ratio_of(segs[i].shift_hz, samplerate), segs[i].n_samples, sn,
                          ctx->variant);
-    dpx::finalize(p->host, p->geom.tile(), ctx->choice);
+    dpx::finalize(p->host, p->geom.tile(), ctx->choice, ctx->tuning);
     hipError_t e = hipSetDevice(ctx->device);
     int rc = e == hipSuccess ? DPX_OK : fail(DPX_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
     if (rc == DPX_OK && p->host.error) rc = fail(DPX_ERR_PLAN, "%s", p->host.error);
@@ -840,7 +869,7 @@ int dpx_stream_submit(dpx_stream *s, size_t in_bytes, const dpx_segment *segs, s
     for (size_t i = 0; i < n_segs; ++i)
         dpx::plan_append(b.plan, dpx::ratio_of(segs[i].shift_hz, s->samplerate), segs[i].n_samples, sn, ctx->variant);
     const dpx::LaunchGeom g = geometry(ctx);
-    dpx::finalize(b.plan, g.tile(), ctx->choice);
+    dpx::finalize(b.plan, g.tile(), ctx->choice, ctx->tuning);
     if (b.plan.error) return fail(DPX_ERR_PLAN, "%s", b.plan.error);
     b.out_bytes = (size_t)total * obs;
     if (total) {

@@ -17,7 +17,7 @@
 #include <stdlib.h>
 
 #include "../../include/doppler_hip.h"
-#include "dpx_sincos.cuh"
+#include "dpx_sincos.h"
 #include "dpx_types.h"
 
 #pragma clang fp contract(off)
@@ -352,7 +352,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
             store_quad<OUT_FMT>(out, t0 + (uint64_t)(v * BLOCK + tid) * SPL, qo);
         }
     } else if (whole && (sg.period == 0 || sg.period >= 4)) {
-        // ---- sincos per sample: periodic with period >= 4, or linear
+        // ---- sincos per sample: periodic with period >= 4, or linear.  A lane's four consecutive counters go
+        // through corrector4 (packed theta products, one fast-path decision per four samples).
         const uint32_t P = sg.period;
         const uint64_t j0 = t0 - sg.first;
         uint32_t base;   // periodic: phase of t0 in [0, P); linear: the counter itself
@@ -360,23 +361,28 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
         else        base = sg.n_start + (uint32_t)j0;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            uint32_t t = base + (uint32_t)(v * BLOCK + tid) * SPL;
-            if (P != 0) t %= P;
+            uint32_t t = base + (uint32_t)(v * BLOCK + tid) * SPL;     // periodic: < P + TILE
+            uint32_t n[SPL];
+            if (P == 0) {
+#pragma unroll
+                for (int k = 0; k < (int)SPL; ++k) n[k] = t + k;         // u32 arithmetic wraps like the reference's `+= 1`
+            } else {
+                if (P >= TILE) t = t >= P ? t - P : t;                   // at most one wrap (uniform branch)
+                else           t %= P;
+#pragma unroll
+                for (int k = 0; k < (int)SPL; ++k) {
+                    const uint32_t e = t + k;                            // P >= 4: at most one wrap
+                    n[k] = (e >= P ? e - P : e) + 1u;
+                }
+            }
+            f32x2 cs[SPL];
+            corrector4<FMA>(sg.ratio, n, cs);
             Quad<OUT_FMT> qo;
 #pragma unroll
             for (int k = 0; k < (int)SPL; ++k) {
-                uint32_t n;
-                if (P != 0) {
-                    uint32_t e = t + k;
-                    e = (e >= P) ? e - P : e;
-                    n = e + 1u;
-                } else {
-                    n = t + k;
-                }
-                float c, s, a, b, re, im;
-                corrector<FMA>(sg.ratio, n, c, s);
+                float a, b, re, im;
                 quad_get<IN_FMT>(qin[v], k, a, b);
-                mix(a, b, c, s, re, im);
+                mix(a, b, cs[k].x, cs[k].y, re, im);
                 quad_set<OUT_FMT>(qo, k, re, im);
             }
             store_quad<OUT_FMT>(out, t0 + (uint64_t)(v * BLOCK + tid) * SPL, qo);
@@ -394,11 +400,14 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
 
 
 // ---- walk kernel: many tabulated stretches in one launch (dpx_types.h, WalkSeg).
-// A workgroup = 5 wavefronts x 2 rows of ONE 256-sample column window: the window's correctors (288 table entries,
-// whatever the rows' shifts) are read from memory once, staged in LDS, and used by all ten rows.  One shot, no loop,
-// no divergent branch: the compiler serialises loads that sit in divergent blocks, so a lane without a sample
-// (past the end of its row, or a row past the end of the matrix) loads from the start of the matrix instead and
-// stores to a scratch area (`sink`).
+// A workgroup = WAVES wavefronts x U rows (U = 1..4, chosen per row chunk by the planner) of ONE 256-sample column
+// window: the window's correctors (288 entries, whatever the rows' shifts) are read from a plan-time table once — or
+// evaluated by the workgroup itself — staged in LDS, and used by all the rows.  One shot, no loop, no divergent
+// branch: the compiler serialises loads that sit in divergent blocks, so a lane without a sample (past the end of its
+// row, or a row past the end of the chunk) loads from the start of the matrix instead and stores to a scratch area
+// (`sink`).  The cost of a workgroup is largely fixed (descriptor fetch, slice, barrier: about 1.2 rows' worth,
+// profiles/r02_walk.md), so the planner makes chunks as tall as a workgroup can take (up to 4 rows per wavefront)
+// instead of leaving short remainder chunks; the rows-per-wavefront switch below is uniform for the workgroup.
 // Walk kernel, f32 -> i16: loads are 16 bytes per lane (2 samples), which would make the stores 8 bytes per lane — and
 // 8-byte stores run at 2.4 TB/s in this kernel (measured; 16-byte stores with two 16-byte loads per lane at a 32-byte
 // lane stride: 5.0 TB/s).  So the packed results of a row go through a wavefront-private kilobyte of LDS and leave as
@@ -408,18 +417,22 @@ template <int IN_FMT, int OUT_FMT> struct WalkVec {
     static constexpr bool kTranspose = IN_FMT == DPX_FMT_F32 && OUT_FMT == DPX_FMT_I16;
 };
 
-template <int IN_FMT, int OUT_FMT, bool FMA, int WAVES, int U, bool COMPUTE>
-__global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restrict__ in,
-                                                            uint8_t *__restrict__ out,
-                                                            const float2 *__restrict__ lut_pool,
-                                                            const WalkSeg *__restrict__ wsegs,
-                                                            const uint32_t *__restrict__ whint,
-                                                            uint32_t n_left_wg,
-                                                            uint8_t *__restrict__ sink,
-                                                            // ---- leftover path only
-                                                            const LeftRange *__restrict__ left,
-                                                            const uint32_t *__restrict__ lhint,
-                                                            const DevSeg *__restrict__ segs)
+// LDS layout of a slice: S planes by entry index modulo S (entry e at plane e % S, position e / S): the S correctors a
+// lane needs for one vector (entries off + S * lane + k) then sit at consecutive 8-byte positions across the lanes for
+// every k — conflict-free ds_read_b64 whatever the row's shift (a plain array read at a lane stride of S entries is
+// 4-way conflicted: 30 % of the LDS cycles in round 1).  The plane stride makes the fills conflict-free as well
+// (planes 16 or 8 banks apart).
+template <int S> struct SlicePlanes {
+    static constexpr uint32_t kPlanes = S, kLog2 = S == 4 ? 2 : 1, kStride = 304 / S;
+    static_assert(kStride * kPlanes >= kWalkSlice + kPlanes && kWalkSlice % kPlanes == 0, "planes hold the slice");
+    static __device__ __forceinline__ uint32_t index(uint32_t e) { return (e & (kPlanes - 1)) * kStride + (e >> kLog2); }
+};
+
+// everything a wavefront does for its U rows of window w (after the descriptor and, in table mode, the slice loads)
+template <int IN_FMT, int OUT_FMT, bool FMA, int WAVES, int U, int TL>
+__device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint8_t *__restrict__ sink,
+                                          const WalkSeg &ws, uint32_t w, uint32_t wave, uint32_t lane, uint32_t tid, bool compute,
+                                          const float2 (&t0)[TL], const float2 (&t1)[TL], float2 *slice, uint32_t *xpose)
 {
     constexpr int S = WalkVec<IN_FMT, OUT_FMT>::S;                // samples per lane per vector: 4 or 2
     constexpr int NV = (int)kWalkWindow / (kRowsLanes * S);       // vectors per lane per row: 1 or 2
@@ -428,29 +441,172 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
     constexpr int QW = S * IB / 4;                                // input dwords per vector
     typedef uint32_t qvec __attribute__((ext_vector_type(QW)));
     constexpr bool XP = WalkVec<IN_FMT, OUT_FMT>::kTranspose;
-    __shared__ float2 slice[kWalkSlice];
-    __shared__ uint32_t xpose[XP ? WAVES * U * (int)kWalkWindow : 1];   // packed i16 samples of one row per (wavefront, u)
+    typedef SlicePlanes<S> SP;
+
+    const uint32_t r0 = ws.row0 + wave * U;
+    // A wavefront past the last row of the chunk has nothing to do; unless it produces part of the slice (the first
+    // kWalkSlice / 2 threads load it, or the first kWalkSlice threads evaluate it) it leaves at once.  s_barrier counts
+    // the wavefronts of the workgroup that have not terminated (CDNA ISA, S_BARRIER: a wave that has ended is no
+    // longer waited for), so the survivors' barrier completes; tests/test_gpu_parity.py runs every workgroup shape
+    // with row counts that leave 1..WAVES-1 wavefronts without rows.
+    // In table mode the first kWalkSlice / 2 threads have requested the slice (16 bytes each) and must deliver it; when
+    // the workgroup evaluates the slice itself, the wavefronts WITH rows share that work among themselves — a
+    // wavefront without rows then holds no slot while the others wait for their samples, which is what keeps short
+    // chunks (matrices of few rows) from starving the CU of loads in flight.
+    const uint32_t n_act = (ws.row_end - ws.row0 + U - 1) / U;          // wavefronts with rows: 1..WAVES (uniform)
+    if (r0 >= ws.row_end && (compute || wave * kRowsLanes >= kWalkSlice / 2)) return;
+    qvec qin[U][NV];
+    uint32_t off[U];                                          // slice entry of the row's column 0 (uniform per wavefront)
+    uint8_t *op[U][NV];
+    uint8_t *opx[U];                                          // f32 -> i16: where this lane's 4 consecutive samples go
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool valid = r0 + u < ws.row_end;
+        const uint64_t ideal = ws.A + (uint64_t)(valid ? r0 + u : 0u) * ws.L;
+        const uint64_t row0 = ideal & ~31ull;                             // whole 128-byte lines on both sides
+        const uint32_t delta = (uint32_t)ideal & 31u;
+        const uint64_t nxt = (ideal + ws.L) & ~31ull;
+        const uint32_t rowlen = valid ? (uint32_t)((nxt < ws.E ? nxt : ws.E) - row0) : 0u;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const uint32_t cl = lane * S + (uint32_t)v * (kRowsLanes * S);   // column inside the window
+            const uint32_t c = w * kWalkWindow + cl;
+            const bool active = c < rowlen;
+            const uint64_t g = active ? row0 + c : ws.A + cl;
+            qin[u][v] = __builtin_nontemporal_load(reinterpret_cast<const qvec *>(in + g * IB));
+            op[u][v] = active ? out + g * OB : sink + tid * 16;
+        }
+        off[u] = kWalkPad - delta;
+        const uint32_t c4 = w * kWalkWindow + lane * 4;
+        opx[u] = c4 < rowlen ? out + (row0 + c4) * OB : sink + tid * 16;
+    }
+
+    if (compute) {                                            // uniform for the workgroup
+        // the threads of the wavefronts with rows evaluate entries tid, tid + 64 n_act, ... with the bit-exact sincos —
+        // after the sample loads above have been issued, so the evaluation runs in the shadow of the HBM latency
+        const uint32_t P = ws.period;
+        // counter of column c: ((phase + c) mod P) + 1, c = 256 w + j - kWalkPad >= -kWalkPad
+        const uint32_t ub = ws.phase + w * kWalkWindow;       // < period + L + 255 < 2^24
+        for (uint32_t j = tid; j < kWalkSlice; j += n_act * kRowsLanes) {
+            uint32_t t;
+            if (ws.L == P) {                                  // P >= kWalkMinL > kWalkPad: at most two wraps
+                t = ub + j + P - kWalkPad;
+                t = t >= 2u * P ? t - 2u * P : t;
+                t = t >= P ? t - P : t;
+                t = t >= P ? t - P : t;
+            } else {
+                t = (uint32_t)(((uint64_t)ub + j + (uint64_t)P * kWalkPad - kWalkPad) % P);
+            }
+            float c, sn;
+            corrector<FMA>(ws.ratio, t + 1u, c, sn);
+            slice[SP::index(j)] = make_float2(c, sn);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TL; ++i) {
+            const uint32_t j = tid + (uint32_t)i * THREADS;
+            if (j < kWalkSlice / 2) {                           // entries 2j and 2j + 1
+                slice[SP::index(2 * j)] = t0[i];
+                slice[SP::index(2 * j + 1)] = t1[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (r0 >= ws.row_end) return;                             // a wavefront past the last row (uniform)
+
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float re[S], im[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                const uint32_t ok = off[u] + (uint32_t)k;     // uniform: plane and base position of corrector k
+                const float2 cs = slice[(ok & (SP::kPlanes - 1)) * SP::kStride + (ok >> SP::kLog2) + (uint32_t)v * kRowsLanes + lane];
+                float a, bq;
+                if constexpr (IN_FMT == DPX_FMT_I16) unpack_i16(qin[u][v][k], a, bq);
+                else { a = __uint_as_float(qin[u][v][2 * k]); bq = __uint_as_float(qin[u][v][2 * k + 1]); }
+                mix(a, bq, cs.x, cs.y, re[k], im[k]);
+            }
+            if constexpr (OUT_FMT == DPX_FMT_I16) {
+                if constexpr (S == 4) {
+                    u32x4 o = {pack_i16(re[0], im[0]), pack_i16(re[1], im[1]), pack_i16(re[2], im[2]),
+                               pack_i16(re[3], im[3])};
+                    asm volatile("" : "+v"(o));   // keeps the vectoriser from rebuilding the store without its nt flag
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(op[u][v]));
+                } else if constexpr (XP) {
+                    u32x2 o;
+                    o[0] = pack_i16(re[0], im[0]);
+                    o[1] = pack_i16(re[1], im[1]);
+                    uint32_t *xp = xpose + (wave * U + u) * kWalkWindow + (uint32_t)v * (kRowsLanes * S) + lane * S;
+                    *reinterpret_cast<u32x2 *>(xp) = o;
+                } else {
+                    u32x2 o;
+                    o[0] = pack_i16(re[0], im[0]);
+                    o[1] = pack_i16(re[1], im[1]);
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x2 *>(op[u][v]));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < S / 2; ++i) {
+                    u32x4 o;
+                    o[0] = __float_as_uint(re[2 * i]);     o[1] = __float_as_uint(im[2 * i]);
+                    o[2] = __float_as_uint(re[2 * i + 1]); o[3] = __float_as_uint(im[2 * i + 1]);
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(op[u][v]) + i);
+                }
+            }
+        }
+        if constexpr (XP) {
+            // the row's 256 packed samples are in LDS (same wavefront: LDS operations execute in order)
+            __builtin_amdgcn_wave_barrier();
+            u32x4 o = *reinterpret_cast<const u32x4 *>(xpose + (wave * U + u) * kWalkWindow + lane * 4);
+            asm volatile("" : "+v"(o));
+            __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(opx[u]));
+        }
+    }
+}
+
+template <int IN_FMT, int OUT_FMT, bool FMA, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restrict__ in,
+                                                            uint8_t *__restrict__ out,
+                                                            const float2 *__restrict__ lut_pool,
+                                                            const WalkSeg *__restrict__ wdesc,
+                                                            uint32_t n_left_wg,
+                                                            uint8_t *__restrict__ sink,
+                                                            // ---- leftover path only
+                                                            const LeftRange *__restrict__ left,
+                                                            const uint32_t *__restrict__ lhint,
+                                                            const DevSeg *__restrict__ segs)
+{
+    constexpr int S = WalkVec<IN_FMT, OUT_FMT>::S;
+    constexpr int THREADS = WAVES * 64;
+    constexpr bool XP = WalkVec<IN_FMT, OUT_FMT>::kTranspose;
+    __shared__ float2 slice[SlicePlanes<S>::kPlanes * SlicePlanes<S>::kStride];
+    __shared__ uint32_t xpose[XP ? WAVES * (int)kWalkMaxRowsPerWave * (int)kWalkWindow : 1];   // packed i16 samples of one row per (wavefront, u)
     const uint32_t tid = threadIdx.x;
 
-    // the leftover workgroups come first in the grid: their sincos work then overlaps the memory-bound matrices
-    // instead of forming a tail
-    if (blockIdx.x >= n_left_wg) {
-        const uint32_t b = blockIdx.x - n_left_wg;
-        // the wavefront index is uniform: telling the compiler so keeps all the row geometry below in scalar registers
+    // ONE scalar load before the first sample load: the descriptor of this group of 8 workgroups — a row chunk of a
+    // matrix (replicated per group; chunks start on multiples of 8 workgroups) or a group of leftover blocks.  The
+    // leftover groups (sincos per sample, VALU-bound) are spread evenly between the chunks by the planner, so that they
+    // run beside memory-bound workgroups.
+    const uint32_t b = blockIdx.x;
+    const WalkSeg ws = wdesc[b >> kWalkHintShift];
+    const uint32_t w = b - ws.wg_base;
+    if (w >= ws.nw) return;                                       // padding
+    if (ws.upw != 0) {
+        // the wavefront index is uniform: telling the compiler so keeps all the row geometry in scalar registers
         const uint32_t lane = tid & (kRowsLanes - 1), wave = __builtin_amdgcn_readfirstlane(tid / kRowsLanes);
-        // two dependent scalar loads before the first sample load: the chunk index (exact: chunks start on multiples of 8
-        // workgroups, one index per 8), then its descriptor
-        const WalkSeg ws = wsegs[whint[b >> kWalkHintShift]];
-        const uint32_t w = b - ws.wg_base;
-        if (w >= ws.nw) return;                                   // chunks are padded to a multiple of 8 workgroups
 
-        // this window's slice of correctors: entry j = corrector of column 256 w + j - kWalkPad.
-        // COMPUTE: thread j evaluates entry j (threads 0..31 also entry 256 + j) with the bit-exact sincos — after the
-        // sample loads below have been issued, so the evaluation runs in the shadow of the HBM latency.
-        // Otherwise the entries come from the plan-time table.
+        // this window's slice of correctors: entry j = corrector of column 256 w + j - kWalkPad; in table mode it comes
+        // from the plan-time table, 16 bytes per thread, requested before the samples
         constexpr int TL = ((int)kWalkSlice / 2 + THREADS - 1) / THREADS;   // 16-byte pieces per thread: 1 (2 for 128 threads)
+        // Where the slice comes from is decided per matrix by the planner (WalkSeg::tab_off): evaluated here by the
+        // workgroup (no table, no table traffic: matrices of few rows, whose table entries would each be used only a few
+        // times), or read from the plan-time table (matrices of many rows: the table is fetched from HBM by the first
+        // chunk and found in the L2 by the others, and costs no arithmetic).
+        const bool compute = ws.tab_off == kWalkNoTable;
         float2 t0[TL], t1[TL];
-        if constexpr (!COMPUTE) {
+        if (!compute) {
             const float2 *tab = lut_pool + ws.tab_off + w * kWalkWindow;
 #pragma unroll
             for (int i = 0; i < TL; ++i) {
@@ -461,122 +617,19 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
                 }
             }
         }
-
-        const uint32_t r0 = ws.row0 + wave * U;
-        // a wavefront past the last row of the matrix has nothing to do; unless it produces part of the slice (the first
-        // kWalkSlice / 2 threads load it, or the first kWalkSlice threads evaluate it) it leaves at once — the barrier
-        // below only counts the wavefronts still alive
-        constexpr uint32_t kSliceThreads = COMPUTE ? kWalkSlice : kWalkSlice / 2;
-        if (r0 >= ws.rows && wave * kRowsLanes >= kSliceThreads) return;
-        qvec qin[U][NV];
-        uint32_t li[U][NV];                                       // index into the slice
-        uint8_t *op[U][NV];
-        uint8_t *opx[U];                                          // f32 -> i16: where this lane's 4 consecutive samples go
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool valid = r0 + u < ws.rows;
-            const uint64_t ideal = ws.A + (uint64_t)(valid ? r0 + u : 0u) * ws.L;
-            const uint64_t row0 = ideal & ~31ull;                             // whole 128-byte lines on both sides
-            const uint32_t delta = (uint32_t)ideal & 31u;
-            const uint64_t nxt = (ideal + ws.L) & ~31ull;
-            const uint32_t rowlen = valid ? (uint32_t)((nxt < ws.E ? nxt : ws.E) - row0) : 0u;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const uint32_t cl = lane * S + (uint32_t)v * (kRowsLanes * S);   // column inside the window
-                const uint32_t c = w * kWalkWindow + cl;
-                const bool active = c < rowlen;
-                const uint64_t g = active ? row0 + c : ws.A + cl;
-                qin[u][v] = __builtin_nontemporal_load(reinterpret_cast<const qvec *>(in + g * IB));
-                li[u][v] = kWalkPad - delta + cl;
-                op[u][v] = active ? out + g * OB : sink + tid * 16;
-            }
-            const uint32_t c4 = w * kWalkWindow + lane * 4;
-            opx[u] = c4 < rowlen ? out + (row0 + c4) * OB : sink + tid * 16;
-        }
-
-        if constexpr (COMPUTE) {
-            const uint32_t P = ws.period;
-            // counter of column c: ((phase + c) mod P) + 1, c = 256 w + j - kWalkPad >= -kWalkPad
-            const uint32_t ub = ws.phase + w * kWalkWindow;       // < period + L + 255 < 2^24
-            for (uint32_t j = tid; j < kWalkSlice; j += THREADS) {
-                uint32_t t;
-                if (ws.L == P) {                                  // P >= kWalkMinL > kWalkPad: at most two wraps
-                    t = ub + j + P - kWalkPad;
-                    t = t >= 2u * P ? t - 2u * P : t;
-                    t = t >= P ? t - P : t;
-                    t = t >= P ? t - P : t;
-                } else {
-                    t = (uint32_t)(((uint64_t)ub + j + (uint64_t)P * kWalkPad - kWalkPad) % P);
-                }
-                float c, sn;
-                corrector<FMA>(ws.ratio, t + 1u, c, sn);
-                slice[j] = make_float2(c, sn);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < TL; ++i) {
-                const uint32_t j = tid + (uint32_t)i * THREADS;
-                if (j < kWalkSlice / 2) {
-                    slice[2 * j] = t0[i];
-                    slice[2 * j + 1] = t1[i];
-                }
-            }
-        }
-        __syncthreads();
-        if (r0 >= ws.rows) return;                                // a wavefront past the last row (uniform)
-
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                float re[S], im[S];
-#pragma unroll
-                for (int k = 0; k < S; ++k) {
-                    const float2 cs = slice[li[u][v] + k];
-                    float a, bq;
-                    if constexpr (IN_FMT == DPX_FMT_I16) unpack_i16(qin[u][v][k], a, bq);
-                    else { a = __uint_as_float(qin[u][v][2 * k]); bq = __uint_as_float(qin[u][v][2 * k + 1]); }
-                    mix(a, bq, cs.x, cs.y, re[k], im[k]);
-                }
-                if constexpr (OUT_FMT == DPX_FMT_I16) {
-                    if constexpr (S == 4) {
-                        u32x4 o = {pack_i16(re[0], im[0]), pack_i16(re[1], im[1]), pack_i16(re[2], im[2]),
-                                   pack_i16(re[3], im[3])};
-                        asm volatile("" : "+v"(o));   // keeps the vectoriser from rebuilding the store without its nt flag
-                        __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(op[u][v]));
-                    } else if constexpr (XP) {
-                        u32x2 o;
-                        o[0] = pack_i16(re[0], im[0]);
-                        o[1] = pack_i16(re[1], im[1]);
-                        uint32_t *xp = xpose + (wave * U + u) * kWalkWindow + (uint32_t)v * (kRowsLanes * S) + lane * S;
-                        *reinterpret_cast<u32x2 *>(xp) = o;
-                    } else {
-                        u32x2 o;
-                        o[0] = pack_i16(re[0], im[0]);
-                        o[1] = pack_i16(re[1], im[1]);
-                        __builtin_nontemporal_store(o, reinterpret_cast<u32x2 *>(op[u][v]));
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < S / 2; ++i) {
-                        u32x4 o;
-                        o[0] = __float_as_uint(re[2 * i]);     o[1] = __float_as_uint(im[2 * i]);
-                        o[2] = __float_as_uint(re[2 * i + 1]); o[3] = __float_as_uint(im[2 * i + 1]);
-                        __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(op[u][v]) + i);
-                    }
-                }
-            }
-            if constexpr (XP) {
-                // the row's 256 packed samples are in LDS (same wavefront: LDS operations execute in order)
-                __builtin_amdgcn_wave_barrier();
-                u32x4 o = *reinterpret_cast<const u32x4 *>(xpose + (wave * U + u) * kWalkWindow + lane * 4);
-                asm volatile("" : "+v"(o));
-                __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(opx[u]));
-            }
+        // rows per wavefront of this chunk: uniform for the workgroup
+        switch (ws.upw) {
+        case 1:  walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 1, TL>(in, out, sink, ws, w, wave, lane, tid, compute, t0, t1, slice, xpose); break;
+        case 2:  walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 2, TL>(in, out, sink, ws, w, wave, lane, tid, compute, t0, t1, slice, xpose); break;
+        case 3:  walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 3, TL>(in, out, sink, ws, w, wave, lane, tid, compute, t0, t1, slice, xpose); break;
+        default: walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 4, TL>(in, out, sink, ws, w, wave, lane, tid, compute, t0, t1, slice, xpose); break;
         }
     } else {
         // ---- leftover ranges: one block of kLeftBlock samples of ONE stretch, sincos per sample
-        const uint32_t e = blockIdx.x;
+#ifdef DPX_DEBUG_SKIP_LEFT      // timing experiments only (wrong output): what the leftover workgroups cost
+        return;
+#endif
+        const uint32_t e = ws.row0 + w;                           // index of this block among all leftover blocks
         uint32_t li = lhint[e >> kLeftHintShift];
         while (left[li + 1].wg_off <= e) ++li;                    // sentinel at the end
         const LeftRange lr = left[li];
@@ -588,23 +641,79 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
         uint32_t base;   // periodic: phase of g0 in [0, P); linear: the counter itself
         if (P != 0) base = (uint32_t)(((uint64_t)(sg.n_start - 1u) + j0) % P);
         else        base = sg.n_start + (uint32_t)j0;
-#pragma unroll 1
-        for (uint32_t o = tid; o < kLeftBlock; o += THREADS) {
-            if (o0 + o >= lr.len) break;
-            uint32_t n;
+        static_assert(kLeftBlock == 4 * 256 && THREADS >= 256, "a leftover block is four samples for each of 256 threads");
+        if (tid >= 256) return;
+        if (o0 + kLeftBlock <= lr.len && (P == 0 || P >= 4)) {
+            // a whole block: four CONSECUTIVE samples per thread, moved as 16-byte vectors (a block starts wherever its
+            // range does, so the vectors are only sample-aligned: the hardware takes unaligned global accesses)
+            constexpr int IB = Fmt<IN_FMT>::kBytes, OB = Fmt<OUT_FMT>::kBytes;
+            typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+            const uint64_t g = g0 + tid * 4u;
+            u32x4_u qv[Fmt<IN_FMT>::kVecs];
+#pragma unroll
+            for (int i = 0; i < Fmt<IN_FMT>::kVecs; ++i) qv[i] = *(reinterpret_cast<const u32x4_u *>(in + g * IB) + i);
+            uint32_t n[4];
+            uint32_t t = base + tid * 4u;
             if (P == 0) {
-                n = base + o;
-            } else if (P >= kLeftBlock) {                         // base < P and o < kLeftBlock: at most one wrap
-                const uint64_t t = (uint64_t)base + o;
-                n = (uint32_t)(t >= P ? t - P : t) + 1u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) n[k] = t + k;
             } else {
-                n = (uint32_t)(((uint64_t)base + o) % P) + 1u;
+                if (P >= kLeftBlock) t = t >= P ? t - P : t;          // base < P: at most one wrap
+                else                 t %= P;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t ee = t + k;                      // P >= 4: at most one wrap
+                    n[k] = (ee >= P ? ee - P : ee) + 1u;
+                }
             }
-            float c, s, a, bq, re, im;
-            corrector<FMA>(sg.ratio, n, c, s);
-            load_one<IN_FMT>(in, g0 + o, a, bq);
-            mix(a, bq, c, s, re, im);
-            store_one<OUT_FMT>(out, g0 + o, re, im);
+            f32x2 cs[4];
+            corrector4<FMA>(sg.ratio, n, cs);
+            Quad<IN_FMT> qi;
+#pragma unroll
+            for (int i = 0; i < Fmt<IN_FMT>::kVecs; ++i) qi.v[i] = qv[i];
+            Quad<OUT_FMT> qo;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a, bq, re, im;
+                quad_get<IN_FMT>(qi, k, a, bq);
+                mix(a, bq, cs[k].x, cs[k].y, re, im);
+                quad_set<OUT_FMT>(qo, k, re, im);
+            }
+#pragma unroll
+            for (int i = 0; i < Fmt<OUT_FMT>::kVecs; ++i) {
+                const u32x4_u o = qo.v[i];
+                *(reinterpret_cast<u32x4_u *>(out + g * OB) + i) = o;
+            }
+        } else {
+            // the last block of a range (or a period below 4): sample by sample, o = tid + k * 256
+            if (o0 + tid >= lr.len) return;
+            uint32_t n[4];
+            bool have[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t o = tid + (uint32_t)k * 256u;
+                have[k] = o0 + o < lr.len;
+                const uint32_t oo = have[k] ? o : tid;
+                if (P == 0) {
+                    n[k] = base + oo;
+                } else if (P >= kLeftBlock) {                         // base < P and o < kLeftBlock: at most one wrap
+                    const uint64_t t = (uint64_t)base + oo;
+                    n[k] = (uint32_t)(t >= P ? t - P : t) + 1u;
+                } else {
+                    n[k] = (uint32_t)(((uint64_t)base + oo) % P) + 1u;
+                }
+            }
+            f32x2 cs[4];
+            corrector4<FMA>(sg.ratio, n, cs);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!have[k]) continue;
+                const uint32_t o = tid + (uint32_t)k * 256u;
+                float a, bq, re, im;
+                load_one<IN_FMT>(in, g0 + o, a, bq);
+                mix(a, bq, cs[k].x, cs[k].y, re, im);
+                store_one<OUT_FMT>(out, g0 + o, re, im);
+            }
         }
     }
 }
@@ -758,35 +867,34 @@ int launch_rows(const void *d_in, int in_fmt, void *d_out, int out_fmt, const De
 }
 
 template <int IN_FMT, int OUT_FMT>
-static int walk_t(const void *d_in, void *d_out, const DevSeg *d_segs, const void *d_lut, const WalkSeg *d_walk,
-                  const uint32_t *d_whint, const LeftRange *d_left, const uint32_t *d_lhint, void *d_sink,
-                  const WalkArgs &w, bool fma, hipStream_t st)
+static int walk_t(const void *d_in, void *d_out, const DevSeg *d_segs, const void *d_lut, const WalkSeg *d_wdesc,
+                  const LeftRange *d_left, const uint32_t *d_lhint, void *d_sink, const WalkArgs &w, bool fma, hipStream_t st)
 {
     const uint8_t *in = static_cast<const uint8_t *>(d_in);
     uint8_t *out = static_cast<uint8_t *>(d_out);
     uint8_t *sink = static_cast<uint8_t *>(d_sink);
     const float2 *lut = static_cast<const float2 *>(d_lut);
-    const uint64_t n_wg = (uint64_t)w.n_walk_wg + w.n_left_wg;
+    const uint64_t n_wg = w.n_walk_wg;            // the whole grid: row chunks and the groups of leftover blocks between them
     if (n_wg == 0) return DPX_OK;
     if (n_wg > 0x7fffffffull) return DPX_ERR_ARG;
     const dim3 grid((uint32_t)n_wg);
-#define DPX_WALK_CASE(WW, UU, CC)                                                                                                          \
-    if (w.waves == WW && w.rows_per_wave == UU && (w.compute_slice != 0) == CC) {                                                         \
-        if (fma) walk_kernel<IN_FMT, OUT_FMT, true, WW, UU, CC><<<grid, WW * 64, 0, st>>>(in, out, lut, d_walk, d_whint, w.n_left_wg, sink, d_left, d_lhint, d_segs);  \
-        else     walk_kernel<IN_FMT, OUT_FMT, false, WW, UU, CC><<<grid, WW * 64, 0, st>>>(in, out, lut, d_walk, d_whint, w.n_left_wg, sink, d_left, d_lhint, d_segs); \
-        return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                                                    \
+#define DPX_WALK_CASE(WW)                                                                                                              \
+    if (w.waves == WW) {                                                                                                               \
+        if (fma) walk_kernel<IN_FMT, OUT_FMT, true, WW><<<grid, WW * 64, 0, st>>>(in, out, lut, d_wdesc, w.n_left_wg, sink, d_left, d_lhint, d_segs);  \
+        else     walk_kernel<IN_FMT, OUT_FMT, false, WW><<<grid, WW * 64, 0, st>>>(in, out, lut, d_wdesc, w.n_left_wg, sink, d_left, d_lhint, d_segs); \
+        return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                                                 \
     }
-    DPX_WALK_CASE(5, 2, false) DPX_WALK_CASE(5, 2, true) DPX_WALK_CASE(4, 2, false) DPX_WALK_CASE(6, 2, false) DPX_WALK_CASE(8, 2, false)
+    DPX_WALK_CASE(5) DPX_WALK_CASE(4) DPX_WALK_CASE(6) DPX_WALK_CASE(8)
 #undef DPX_WALK_CASE
     return DPX_ERR_ARG;
 }
 
 int launch_walk(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs, const void *d_lut,
-                const WalkSeg *d_walk, const uint32_t *d_walk_hint, const LeftRange *d_left,
-                const uint32_t *d_left_hint, void *d_sink, const WalkArgs &w, bool fma, void *stream)
+                const WalkSeg *d_walk_desc, const LeftRange *d_left, const uint32_t *d_left_hint, void *d_sink,
+                const WalkArgs &w, bool fma, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    DPX_DISPATCH_FMT(walk_t, d_in, d_out, d_segs, d_lut, d_walk, d_walk_hint, d_left, d_left_hint, d_sink, w, fma, st);
+    DPX_DISPATCH_FMT(walk_t, d_in, d_out, d_segs, d_lut, d_walk_desc, d_left, d_left_hint, d_sink, w, fma, st);
 }
 
 int launch_build_lut(void *d_lut_entries, uint32_t period, uint32_t n_first, uint32_t n_entries,

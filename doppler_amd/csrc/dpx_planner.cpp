@@ -146,13 +146,13 @@ uint64_t lcm_u64(uint64_t a, uint64_t b)
 //     or more than 128 KiB apart);
 //   idle lanes in the last 256-sample column slice: proportional.
 // At least 16 row groups must fit.  Returns 0 if no such L exists.
-uint32_t pick_row_length(uint32_t P, uint64_t body, uint32_t R)
+uint32_t pick_row_length(uint32_t P, uint64_t body, uint32_t R, const PlanTuning &tn)
 {
     uint64_t cap = std::min<uint64_t>(kRowsMaxL, body / (16ull * R));
-    if (const char *e = getenv("DPX_ROWS_MAXL")) cap = std::min<uint64_t>(cap, strtoull(e, nullptr, 0));   // measurement override
+    if (tn.rows_maxl) cap = std::min<uint64_t>(cap, tn.rows_maxl);            // measurement override
     const uint64_t steps[3] = {lcm_u64(P, 1024), lcm_u64(P, 32), lcm_u64(P, 4)};
-    if (const char *e = getenv("DPX_ROWS_MULT")) {   // measurement override: L = mult * lcm(P, 4)
-        const uint64_t L = steps[2] * (uint64_t)atoi(e);
+    if (tn.rows_mult) {                                                        // measurement override: L = mult * lcm(P, 4)
+        const uint64_t L = steps[2] * (uint64_t)tn.rows_mult;
         return (L >= steps[2] && L <= cap) ? (uint32_t)L : 0;
     }
     uint32_t best = 0;
@@ -176,40 +176,28 @@ uint32_t pick_row_length(uint32_t P, uint64_t body, uint32_t R)
 
 // rows per wavefront: 2 while one period of correctors stays L1/L2-hot, 4 for large tables
 // (measured, GB/s at R = 2 / 4 / 8: 8 KB table 6615 / 6264 / 6194; 876 KB table 5406 / 5660 / 5777)
-uint32_t pick_rows_per_wave(uint32_t P)
+uint32_t pick_rows_per_wave(uint32_t P, const PlanTuning &tn)
 {
     uint32_t R = ((uint64_t)P + 3) * 8 <= (128u << 10) ? 2 : 4;
-    if (const char *e = getenv("DPX_ROWS_R")) R = (uint32_t)atoi(e);   // measurement override
+    if (tn.rows_r) R = tn.rows_r;                                              // measurement override
     return (R == 2 || R == 4 || R == 8) ? R : 2;
 }
 
 struct Interval { uint64_t lo, hi; };
 
-static const uint64_t kWalkTileMin = [] { const char *e = getenv("DPX_WALK_TILEMIN"); return e ? strtoull(e, nullptr, 0) : (1ull << 22); }();      // an uncovered gap at least this long gets its own tile launch ...
+// walk kernel: a matrix with at least this many rows gets a plan-time table (each entry is then used that many times:
+// little traffic, no arithmetic); the workgroups of shorter matrices evaluate their slices themselves (profiles/r02_walk.md)
+constexpr uint32_t kWalkTableRows = 0xffffffffu;   // never: evaluating the slices measured at least as fast on every plan shape tried
+constexpr uint64_t kWalkTileMinDefault = 1ull << 22;   // an uncovered gap at least this long gets its own tile launch ...
 constexpr size_t kWalkMaxTileLaunches = 8;       // ... up to this many; the rest is evaluated by leftover workgroups
 
 struct WalkShape { uint32_t waves, rows_per_wave; };
-WalkShape walk_shape()
+WalkShape walk_shape(const PlanTuning &tn)
 {
-    static const WalkShape shape = [] {
-        WalkShape g = {kWalkWaves, kWalkRowsPerWave};
-        if (const char *e = getenv("DPX_WALK_SHAPE")) {             // measurement override: "waves,rows"
-            int a = 0, b = 0;
-            if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) g = {(uint32_t)a, (uint32_t)b};
-        }
-        return g;
-    }();
-    return shape;
-}
-
-// The walk kernel's workgroups read their 288 correctors from plan-time tables (default), or evaluate them themselves
-// with the bit-exact sincos while their sample loads are in flight (DPX_WALK_COMPUTE=1: no tables, no table traffic).
-// Measured on the 600 s replay: tables 5430 GB/s, on-the-fly 5200 GB/s (median; its best launches match) — the f64
-// work costs more than the 16 % of extra reads it removes.
-bool walk_computes_slices()
-{
-    static const bool compute = [] { const char *e = getenv("DPX_WALK_COMPUTE"); return e && atoi(e) != 0; }();
-    return compute;
+    WalkShape g = {kWalkWaves, kWalkRowsPerWave};
+    if (tn.walk_waves) g.waves = tn.walk_waves;                                // measurement overrides
+    if (tn.walk_rows) g.rows_per_wave = std::min(tn.walk_rows, kWalkMaxRowsPerWave);
+    return g;
 }
 
 // matrix of the walk kernel for one stretch (dpx_types.h, WalkSeg); false if the stretch does not qualify
@@ -237,30 +225,30 @@ bool walk_geometry(const DevSeg &s, WalkSeg *w)
     w->period = s.period;
     w->phase = counter_at(s, A - s.first) - 1u;
     w->ratio = s.ratio;
-    w->pad[0] = w->pad[1] = w->pad[2] = 0;
+    w->upw = 0;
+    w->row_end = 0;
+    w->pad = 0;
     return true;
 }
 
-uint32_t walk_chunks(const WalkSeg &w)
+uint32_t walk_chunks(const WalkSeg &w, const PlanTuning &tn)
 {
-    const uint32_t rpw = walk_shape().waves * walk_shape().rows_per_wave;
+    const uint32_t rpw = walk_shape(tn).waves * walk_shape(tn).rows_per_wave;
     return (uint32_t)(((uint64_t)w.rows + rpw - 1) / rpw);
 }
 
-uint64_t walk_workgroups(const WalkSeg &w)
+uint64_t walk_workgroups(const WalkSeg &w, const PlanTuning &tn)
 {
-    return (uint64_t)((w.nw + 7) & ~7u) * walk_chunks(w);     // every chunk padded to a multiple of 8 workgroups
+    return (uint64_t)((w.nw + 7) & ~7u) * walk_chunks(w, tn);     // every chunk padded to a multiple of 8 workgroups
 }
-
-// stretches whose chunks are interleaved in dispatch order.  Measured (profiles/r01_secondary_workloads.md): the slices
-// of a stretch's later chunks are L2 hits already with the chunks adjacent (FETCH_SIZE = samples + the tables once);
-// interleaving 8 stretches changes nothing there and costs 10 % on short-period plans (less contiguous sweeps), so: 1.
-constexpr size_t kWalkGroup = 1;
 
 }  // namespace
 
-void finalize(PlanResult &plan, uint32_t tile, int choice)
+void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
 {
+    // which matrices of a walk launch get a plan-time table (the others' workgroups evaluate their slices themselves)
+    const uint32_t table_rows = tn.walk_compute == 0 ? 0u : tn.walk_compute > 0 ? 0xffffffffu : (tn.walk_table_rows ? tn.walk_table_rows : kWalkTableRows);
+    const uint64_t kWalkTileMin = tn.walk_tilemin ? tn.walk_tilemin : kWalkTileMinDefault;
     plan.tile = tile;
     plan.error = nullptr;
     plan.tables.clear();
@@ -283,8 +271,8 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
         // matrix origin on a 256-sample boundary: 1 KiB of i16 / 2 KiB of f32 per wavefront, aligned
         *A = (s.first + 255) & ~255ull;
         if (*A >= end) return false;
-        *R = pick_rows_per_wave(s.period);
-        *L = pick_row_length(s.period, end - *A, *R);
+        *R = pick_rows_per_wave(s.period, tn);
+        *L = pick_row_length(s.period, end - *A, *R, tn);
         return *L != 0;
     };
     bool use_rows = false, use_walk = false;
@@ -303,7 +291,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
             WalkSeg w;
             if (!walk_geometry(s, &w)) continue;
             in_matrices += w.E - w.A;
-            n_wg += walk_workgroups(w);
+            n_wg += walk_workgroups(w, tn);
         }
         // worth it when most of the stream is in matrices (the rest is evaluated sample by sample)
         use_walk = in_matrices > 0 && in_matrices >= plan.n_samples / 2 && n_wg < 0x40000000ull;
@@ -415,8 +403,8 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
                 continue;
             }
             s.flags |= kSegWalk;
-            w.tab_off = 0;
-            if (!walk_computes_slices()) {
+            w.tab_off = kWalkNoTable;
+            if (w.rows >= table_rows) {
                 // entry x = corrector of column x - kWalkPad, column 0 = sample A
                 w.tab_off = (uint32_t)pool;
                 const uint32_t P = s.period;
@@ -429,24 +417,6 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
             if (s.first < w.A) uncovered(s.first, w.A, (uint32_t)i);
             if (w.E < end) uncovered(w.E, end, (uint32_t)i);
             covered.push_back({w.A, w.E});
-        }
-        // dispatch order: stretch by stretch, chunk by chunk, window fastest (a chunk sweeps its ten rows contiguously);
-        // every chunk is padded to a multiple of 8 workgroups so that window w of every chunk runs on XCD w % 8
-        uint64_t wg = 0;
-        const uint32_t rpw = walk_shape().waves * walk_shape().rows_per_wave;
-        for (size_t g0 = 0; g0 < mats.size(); g0 += kWalkGroup) {
-            const size_t g1 = std::min(mats.size(), g0 + kWalkGroup);
-            uint32_t max_chunks = 0;
-            for (size_t m = g0; m < g1; ++m) max_chunks = std::max(max_chunks, walk_chunks(mats[m]));
-            for (uint32_t c = 0; c < max_chunks; ++c)
-                for (size_t m = g0; m < g1; ++m) {
-                    if (c >= walk_chunks(mats[m])) continue;
-                    WalkSeg w = mats[m];
-                    w.row0 = c * rpw;
-                    w.wg_base = (uint32_t)wg;
-                    wg += (w.nw + 7) & ~7u;
-                    plan.walk.push_back(w);
-                }
         }
         // uncovered pieces that touch form a gap; long gaps become tile launches, the rest leftover ranges
         std::vector<Interval> gaps_for_tiles;
@@ -470,20 +440,63 @@ void finalize(PlanResult &plan, uint32_t tile, int choice)
             }
             i = j;
         }
-        if (wg + left_wg > 0x7fffffffull) plan.error = "stream needs more than 2^31 workgroups";
+        // dispatch order: stretch by stretch, chunk by chunk, window fastest (a chunk sweeps its rows contiguously);
+        // every chunk is padded to a multiple of 8 workgroups so that window w of every chunk runs on XCD w % 8.
+        // A workgroup costs about the same whatever it holds (profiles/r02_walk.md), so a matrix becomes as few chunks as
+        // the workgroup shape allows, of equal height, each with its own rows-per-wavefront count.
+        // The leftover workgroups (sincos per sample: VALU-bound) are dealt out in groups of 8 between the chunks, evenly
+        // over the grid, so that their arithmetic runs beside memory-bound matrix workgroups on every CU instead of in a
+        // block of its own (all at the front: 5-8 % of the 600-second replay for 1 % of its samples; at the end: worse).
+        const uint32_t waves = walk_shape(tn).waves, max_upw = walk_shape(tn).rows_per_wave;
+        uint64_t m_groups = 0;
+        for (const WalkSeg &m : mats) m_groups += (uint64_t)((m.nw + 7) / 8) * walk_chunks(m, tn);
+        const uint64_t l_groups = (left_wg + 7) / 8;
+        uint64_t wg = 0, m_done = 0, l_done = 0;
+        auto deal_leftovers = [&](uint64_t upto) {          // leftover groups [l_done, upto) go here
+            for (; l_done < upto; ++l_done) {
+                WalkSeg g;
+                memset(&g, 0, sizeof g);
+                g.wg_base = (uint32_t)wg;
+                g.row0 = (uint32_t)(l_done * 8);                                        // first leftover block of the group
+                g.nw = (uint32_t)std::min<uint64_t>(8, left_wg - l_done * 8);
+                g.upw = 0;                                                                // marks a leftover group
+                wg += 8;
+                plan.walk.push_back(g);
+            }
+        };
+        for (size_t mi = 0; mi < mats.size(); ++mi) {
+            const uint32_t k = walk_chunks(mats[mi], tn);
+            for (uint32_t c = 0; c < k; ++c) {
+                WalkSeg w = mats[mi];
+                const uint32_t base = w.rows / k, rem = w.rows % k;
+                const uint32_t h = base + (c < rem ? 1u : 0u);
+                w.row0 = c * base + std::min(c, rem);
+                w.row_end = w.row0 + h;
+                w.upw = std::max(std::min(2u, max_upw), (h + waves - 1) / waves);
+                w.wg_base = (uint32_t)wg;
+                wg += (w.nw + 7) & ~7u;
+                plan.walk.push_back(w);
+                m_done += (w.nw + 7) / 8;
+                deal_leftovers(m_groups ? l_groups * m_done / m_groups : 0);
+            }
+        }
+        deal_leftovers(l_groups);
+        if (wg > 0x7fffffffull) plan.error = "stream needs more than 2^31 workgroups";
         Launch ln;
         ln.kind = 2;
-        ln.walk.n_walk_wg = (uint32_t)wg;
-        ln.walk.n_left_wg = (uint32_t)left_wg;
+        ln.walk.n_walk_wg = (uint32_t)wg;            // the whole grid, leftover groups included
+        ln.walk.n_left_wg = (uint32_t)left_wg;       // leftover blocks among them
         ln.walk.n_segs = (uint32_t)ns;
-        ln.walk.waves = walk_shape().waves;
-        ln.walk.rows_per_wave = walk_shape().rows_per_wave;
-        ln.walk.compute_slice = walk_computes_slices() ? 1u : 0u;
+        ln.walk.waves = walk_shape(tn).waves;
+        ln.walk.rows_per_wave = walk_shape(tn).rows_per_wave;
+        ln.walk.compute_slice = 0;
+        for (const WalkSeg &m : mats) if (m.tab_off == kWalkNoTable) ln.walk.compute_slice = 1;
         plan.launches.push_back(ln);
         // sentinels end the kernels' forward scans; hints give the scan its starting point
         WalkSeg wend;
         memset(&wend, 0, sizeof wend);
         wend.wg_base = 0xffffffffu;
+        wend.upw = 1;
         plan.walk.push_back(wend);
         plan.left.push_back({0, 0, 0, 0xffffffffu, 0});
         const uint64_t n_wh = (wg >> kWalkHintShift) + 1;
@@ -599,13 +612,26 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
             for (uint32_t b = 0; b < wa.n_walk_wg; ++b) {
                 const WalkSeg &ws = plan.walk[plan.walk_hint[b >> kWalkHintShift]];
                 if (b < ws.wg_base || b - ws.wg_base >= ((ws.nw + 7u) & ~7u)) { put(0, 0xfffffffcu); continue; }   // hint not exact
-                const TableBuild *tb = nullptr;
-                for (const TableBuild &t : plan.tables) if (t.off == ws.tab_off) tb = &t;
                 const uint32_t w = b - ws.wg_base;
                 if (w >= ws.nw) continue;
-                const uint32_t r_lo = ws.row0;
-                const uint32_t r_hi = (uint32_t)std::min<uint64_t>(ws.rows, (uint64_t)r_lo + wa.waves * wa.rows_per_wave);
-                for (uint32_t r = r_lo; r < r_hi; ++r) {
+                if (ws.upw == 0) {                                                 // a group of leftover blocks
+                    const uint32_t e = ws.row0 + w;
+                    if (e >= wa.n_left_wg) { put(0, 0xfffffffau); continue; }
+                    uint32_t li = plan.left_hint[e >> kLeftHintShift];
+                    while (plan.left[li + 1].wg_off <= e) ++li;
+                    const LeftRange &lr = plan.left[li];
+                    const DevSeg &sg = plan.segs[lr.seg];
+                    const uint32_t o0 = (e - lr.wg_off) * kLeftBlock;
+                    for (uint32_t o = 0; o < kLeftBlock && o0 + o < lr.len; ++o) {
+                        const uint64_t g = lr.start + o0 + o;
+                        put(g, counter_at(sg, g - sg.first));
+                    }
+                    continue;
+                }
+                const TableBuild *tb = nullptr;
+                for (const TableBuild &t : plan.tables) if (t.off == ws.tab_off) tb = &t;
+                if (ws.upw < 1 || ws.upw > wa.rows_per_wave || ws.row_end > ws.rows || ws.row_end - ws.row0 > wa.waves * ws.upw) { put(0, 0xfffffffbu); continue; }
+                for (uint32_t r = ws.row0; r < ws.row_end; ++r) {
                     const uint64_t ideal = ws.A + (uint64_t)r * ws.L;
                     const uint64_t row0 = ideal & ~31ull;
                     const uint32_t delta = (uint32_t)ideal & 31u;
@@ -616,7 +642,7 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
                         if (c >= rowlen) break;                                   // lanes past the row store to the sink
                         const uint32_t j = kWalkPad - delta + cl;                 // index in the slice
                         if (j >= kWalkSlice) { put(row0 + c, 0xffffffffu); continue; }
-                        if (wa.compute_slice) {                                   // the kernel's own counter arithmetic
+                        if (ws.tab_off == kWalkNoTable) {                         // the kernel's own counter arithmetic
                             const uint32_t P = ws.period;
                             const uint32_t ub = ws.phase + w * kWalkWindow;
                             uint32_t t;
@@ -633,20 +659,9 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
                             continue;
                         }
                         const uint32_t x = w * kWalkWindow + j;                   // table index
-                        if (x >= tb->n_entries) { put(row0 + c, 0xffffffffu); continue; }
+                        if (!tb || x >= tb->n_entries) { put(row0 + c, 0xffffffffu); continue; }
                         put(row0 + c, (uint32_t)(((uint64_t)(tb->n_first - 1u) + x) % tb->period) + 1u);
                     }
-                }
-            }
-            for (uint32_t e = 0; e < wa.n_left_wg; ++e) {
-                uint32_t li = plan.left_hint[e >> kLeftHintShift];
-                while (plan.left[li + 1].wg_off <= e) ++li;
-                const LeftRange &lr = plan.left[li];
-                const DevSeg &sg = plan.segs[lr.seg];
-                const uint32_t o0 = (e - lr.wg_off) * kLeftBlock;
-                for (uint32_t o = 0; o < kLeftBlock && o0 + o < lr.len; ++o) {
-                    const uint64_t g = lr.start + o0 + o;
-                    put(g, counter_at(sg, g - sg.first));
                 }
             }
         } else {

@@ -45,6 +45,20 @@ enum KernelChoice {
     kChooseRows = 3,      // rows kernel or tiles, never the walk kernel (measurement A/B)
 };
 
+// Measurement knobs of finalize() (dpx_set_option; 0 = the planner's own choice everywhere).  None of them changes
+// a result, only which kernel shape produces it.
+struct PlanTuning {
+    uint32_t rows_mult = 0;      // rows kernel: row length = rows_mult * lcm(period, 4)
+    uint32_t rows_maxl = 0;      // rows kernel: longest row considered
+    uint32_t rows_r = 0;         // rows kernel: rows per wavefront (2, 4 or 8)
+    uint32_t walk_waves = 0;     // walk kernel: wavefronts per workgroup (4, 5, 6 or 8) ...
+    uint32_t walk_rows = 0;      // ... and rows per wavefront (2)
+    uint64_t walk_tilemin = 0;   // walk plans: an uncovered gap at least this long gets its own tile launch
+    int walk_compute = -1;       // walk kernel: 1 = workgroups always evaluate their corrector slices, 0 = always read
+                                 // plan-time tables, -1 = per matrix: tables from walk_table_rows rows on
+    uint32_t walk_table_rows = 0;  // that threshold (0 = the planner's default)
+};
+
 struct PlanResult {
     std::vector<DevSeg> segs;   // consecutive, covering [0, n_samples)
     uint64_t n_samples = 0;
@@ -68,7 +82,7 @@ void plan_append(PlanResult &plan, float ratio, uint64_t count, uint32_t &sample
 
 // after the last plan_append: choose the kernel for every stretch, lay out the
 // corrector tables, build the hint table and the launch list.
-void finalize(PlanResult &plan, uint32_t tile, int choice /* KernelChoice */);
+void finalize(PlanResult &plan, uint32_t tile, int choice /* KernelChoice */, const PlanTuning &tuning = PlanTuning());
 
 // Host mirror of the kernels' index arithmetic (no arithmetic on samples): for every
 // sample of a finalized plan, the counter value the launches would use, and how many

@@ -1,0 +1,373 @@
+// dpx_sincos.h — device sincosf that is bit-identical to glibc 2.35's.
+//
+// The reference builds its corrector with libm: src/dsp.rs:121-122 ->
+// src/complex.c:35 cexpf(0 + i*theta), which for a zero real part is
+// (cosf(theta), sinf(theta)) from glibc's sincosf (Szabolcs Nagy's
+// optimized-routines algorithm: double-precision polynomial, three argument
+// ranges).  "Within 1 ulp" of the output cannot be met with a different
+// sincos (theta reaches tens to thousands of radians, and the complex multiply
+// cancels), so this file evaluates the same double-precision operation
+// sequence, with the same products fused as the x86-64 FMA build of libm fuses
+// them (FMA=true) or none fused (FMA=false, the SSE2 build).
+//
+// The polynomial coefficients, the 2/pi and pi/2 constants, the 4/pi bit string
+// and the 2^(i/32) table below are the published constants of that algorithm
+// (glibc 2.35 sysdeps/ieee754/flt-32/{s_sincosf.h,s_sincosf_data.c,e_exp2f_data.c}):
+//   Copyright (C) 2018-2022 Free Software Foundation, Inc. — GNU Lesser General
+//   Public License 2.1 or later; originally ARM optimized-routines,
+//   Copyright (c) 2018 Arm Ltd., MIT licence ("Permission is hereby granted, free of
+//   charge, to any person obtaining a copy of this software ... to deal in the
+//   Software without restriction ... THE SOFTWARE IS PROVIDED "AS IS", WITHOUT
+//   WARRANTY OF ANY KIND").  Only the constants and the operation order are taken
+//   over (they ARE the function being reproduced); the code around them is written
+//   for 64-wide wavefronts.
+//
+// Structure for a 64-wide wavefront.  Every VALU instruction here costs the same
+// four cycles per wavefront, f64 included (measured, profiles/r02_valubench.md), so
+// the function is priced in instructions:
+//   * fast path, taken when EVERY active lane has 2^-12 <= |y| < 120 (one ballot,
+//     a wave-uniform branch): quadrant reduction + the two polynomials and nothing
+//     else — no range selects, no clamps (31 instructions);
+//   * general path otherwise.  |y| < 2^-12 ("tiny") and inf/nan are per-lane
+//     selects; the "< pi/4" range goes through the quadrant-reduction formula,
+//     which yields quadrant 0 and an unchanged argument there (n*hpi = 0), so it
+//     is exactly the direct polynomial; |y| >= 120 uses the 32x96-bit fixed-point
+//     product with 4/pi, whose three 32-bit windows are cut out of the bit string
+//     with 64-bit register shifts (no memory access: a table load in the middle
+//     of the function would queue behind the kernel's sample loads — vmcnt is
+//     in-order — and serialise the arithmetic behind HBM latency).  Only
+//     |y| >= 2^33, which no stream produces (|theta| < 2^26), reads the table.
+// The two polynomial tables of glibc (cos / -cos) and the sign[] table are
+// replaced by exact sign flips of the results (round-to-nearest is symmetric).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace dpx {
+
+// 4/pi in overlapping 32-bit windows (glibc __inv_pio4), 192 bits
+__device__ __constant__ const uint32_t kInvPio4[24] = {
+    0xa2,       0xa2f9,     0xa2f983,   0xa2f9836e, 0xf9836e4e, 0x836e4e44,
+    0x6e4e4415, 0x4e441529, 0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1,
+    0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0, 0x34ddc0db, 0xddc0db62,
+    0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041,
+};
+
+template <bool FMA>
+__device__ __forceinline__ double mad(double a, double b, double c)
+{
+    if constexpr (FMA) {
+        return __builtin_fma(a, b, c);
+    } else {
+        double p = a * b;   // contract(off): two roundings
+        return p + c;
+    }
+}
+
+// quadrant reduction for |x| < 120 (glibc: ranges "< pi/4" and "< 120"):
+// n = round(x * 2/pi) via a scaled truncating conversion, xr = x - n*pi/2
+template <bool FMA>
+__device__ __forceinline__ double reduce_small(double x, uint32_t &n_out)
+{
+    constexpr double HPI_INV = 0x1.45F306DC9C883p+23;   // 2/pi * 2^24
+    constexpr double HPI = 0x1.921FB54442D18p0;         // pi/2
+    const double r = x * HPI_INV;
+    const int n = (__double2int_rz(r) + 0x800000) >> 24;
+    const double nd = (double)n;
+    n_out = (uint32_t)n;
+    if constexpr (FMA) return __builtin_fma(-nd, HPI, x);
+    else               return x - nd * HPI;
+}
+
+// the two polynomials on the reduced argument, then quadrant signs and the sin/cos exchange.
+// glibc: argument * sign[sidx&3] with sign = {+,-,-,+}; table[1] (sidx&2) is -cos; odd quadrants trade places.
+template <bool FMA>
+__device__ __forceinline__ void sincos_poly(double xr, uint32_t quad, uint32_t sidx, float &rs, float &rc)
+{
+    constexpr double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5,
+                     C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+    constexpr double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7,
+                     S3 = -0x1.994eb3774cf24p-13;
+    const double x2 = xr * xr;
+    const double x3 = x2 * xr;
+    const double x4 = x2 * x2;
+    const double c2 = mad<FMA>(x2, C4, C3);
+    const double s1 = mad<FMA>(x2, S3, S2);
+    const double c1 = mad<FMA>(x2, C1, C0);
+    const double x5 = x3 * x2;
+    const double x6 = x4 * x2;
+    const double s = mad<FMA>(x3, S1, xr);
+    const double c = mad<FMA>(x4, C2, c1);
+    uint32_t fs = __float_as_uint((float)mad<FMA>(x5, s1, s));
+    uint32_t fc = __float_as_uint((float)mad<FMA>(x6, c2, c));
+    const uint32_t t = sidx << 30;                       // bit 31 = sidx & 2
+    fs ^= (t + 0x40000000u) & 0x80000000u;               // ((sidx + 1) & 2) << 30
+    fc ^= t & 0x80000000u;
+    const bool swap = (quad & 1u) != 0;
+    rs = __uint_as_float(swap ? fc : fs);
+    rc = __uint_as_float(swap ? fs : fc);
+}
+
+// |y| >= 120: exact 32x96-bit fixed-point product with 4/pi (glibc reduce_large).
+// IN_REGS: the caller has established that every active lane has |y| < 2^33 (window offset <= 3).
+template <bool IN_REGS>
+__device__ __forceinline__ double reduce_large(uint32_t xi, uint32_t &quad, uint32_t &sidx)
+{
+    constexpr double PI63 = 0x1.921FB54442D18p-62;
+    const uint32_t idx = (xi >> 26) & 15u;               // byte offset of the 96-bit window in the 4/pi string
+    uint32_t a0, a4, a8;
+    if (IN_REGS || __builtin_amdgcn_ballot_w64(idx > 3u) == 0) {
+        // the string's first 16 bytes, big-endian: 000000a2 f9836e4e 441529fc 2757d1f5; window k = bytes idx+4k .. idx+4k+3
+        const uint32_t sh = idx * 8u;
+        a0 = (uint32_t)((0x000000a2f9836e4eull << sh) >> 32);
+        a4 = (uint32_t)((0xf9836e4e441529fcull << sh) >> 32);
+        a8 = (uint32_t)((0x441529fc2757d1f5ull << sh) >> 32);
+    } else {
+        const uint32_t *arr = &kInvPio4[idx];
+        a0 = arr[0];
+        a4 = arr[4];
+        a8 = arr[8];
+    }
+    const uint32_t shift = (xi >> 23) & 7u;
+    uint32_t m = (xi & 0xffffffu) | 0x800000u;
+    m <<= shift;
+    uint64_t res0 = (uint32_t)(m * a0);
+    const uint64_t res1 = (uint64_t)m * a4;
+    const uint64_t res2 = (uint64_t)m * a8;
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t n = (res0 + (1ULL << 61)) >> 62;
+    res0 -= n << 62;
+    quad = (uint32_t)n;
+    sidx = (uint32_t)n + (xi >> 31);
+    return (double)(int64_t)res0 * PI63;
+}
+
+template <bool FMA>
+__device__ __forceinline__ void sincosf_general(float y, float &sn, float &cs);
+
+// sin and cos of y, bit-identical to glibc 2.35 sincosf (see header comment).
+// Must be called from converged or divergent code alike: the ballots below see the active lanes only.
+template <bool FMA>
+__device__ __forceinline__ void sincosf_glibc(float y, float &sn, float &cs)
+{
+    const uint32_t xi = __float_as_uint(y);
+    const uint32_t ax = xi & 0x7fffffffu;
+    // 2^-12 <= |y| < 120 (0x39800000 = 2^-12, 0x42f00000 = 120)
+    const bool plain = (ax - 0x39800000u) < (0x42f00000u - 0x39800000u);
+    if (__builtin_amdgcn_ballot_w64(!plain) == 0) {
+        uint32_t n;
+        const double xr = reduce_small<FMA>((double)y, n);
+        sincos_poly<FMA>(xr, n, n, sn, cs);
+        return;
+    }
+    // 120 <= |y| < 2^33: every lane takes the fixed-point reduction with the windows cut from registers
+    // (the common case for a stream: theta = 2 pi ratio n passes 120 after a few thousand counters)
+    const bool large = (ax - 0x42f00000u) < (0x50000000u - 0x42f00000u);
+    if (__builtin_amdgcn_ballot_w64(!large) == 0) {
+        uint32_t quad, sidx;
+        const double xr = reduce_large<true>(xi, quad, sidx);
+        sincos_poly<FMA>(xr, quad, sidx, sn, cs);
+        return;
+    }
+    sincosf_general<FMA>(y, sn, cs);
+}
+
+// any mixture of ranges in one wavefront: per-lane selects
+template <bool FMA>
+__device__ __forceinline__ void sincosf_general(float y, float &sn, float &cs)
+{
+    const uint32_t xi = __float_as_uint(y);
+    const uint32_t top = xi >> 20 & 0x7ffu;             // abstop12
+    // clamp keeps the conversion defined for lanes that take another range
+    uint32_t quad, sidx;
+    double xr = reduce_small<FMA>((top < 0x42fu) ? (double)y : 0.0, quad);
+    sidx = quad;
+    if (top >= 0x42fu && top < 0x7f8u) xr = reduce_large<false>(xi, quad, sidx);
+    float rs, rc;
+    sincos_poly<FMA>(xr, quad, sidx, rs, rc);
+    if (top < 0x398u) {          // |y| < 2^-12: sin = y, cos = 1
+        rs = y;
+        rc = 1.0f;
+    }
+    if (top >= 0x7f8u) {         // inf / nan
+        rs = rc = y - y;
+    }
+    sn = rs;
+    cs = rc;
+}
+
+// 2^(i/32) as IEEE-754 doubles (glibc __exp2f_data.tab)
+__device__ __constant__ const uint64_t kExp2fTab[32] = {
+    0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b,
+    0x3fef54873168b9aa, 0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb,
+    0x3feedea64c123422, 0x3feece086061892d, 0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429,
+    0x3feea47eb03a5585, 0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74, 0x3feea11473eb0187, 0x3feea589994cce13,
+    0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d, 0x3feee89f995ad3ad,
+    0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f,
+    0x3fefa4afa2a490da, 0x3fefd0765b6e4540,
+};
+
+// expf, bit-identical to glibc 2.35 (optimized-routines expf: x*32/ln2 = k + r, 2^(k/32) from the
+// table, cubic in r, all in double).  Not on the streaming path: ccexpf arguments with a real
+// part only (reference src/dsp.rs:57-83).
+template <bool FMA>
+__device__ __forceinline__ float expf_glibc(float x)
+{
+    constexpr double SHIFT = 0x1.8p+52, INVLN2N = 0x1.71547652b82fep+5;
+    constexpr double C0 = 0x1.c6af84b912394p-20, C1 = 0x1.ebfce50fac4f3p-13, C2 = 0x1.62e42ff0c52d6p-6;
+    const uint32_t xi = __float_as_uint(x);
+    const uint32_t abstop = (xi >> 20) & 0x7ffu;
+    if (abstop >= 0x42bu) {                       // |x| >= 88 or nan
+        if (xi == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8u) return x + x;
+        if (x > 0x1.62e42ep6f) return __uint_as_float(0x7f800000u);    // 0x1p97f * 0x1p97f
+        if (x < -0x1.9fe368p6f) return 0.0f;                           // 0x1p-95f * 0x1p-95f
+        if (x < -0x1.9d1d9ep6f) return __uint_as_float(1u);            // 0x1.4p-75f squared rounds to 2^-149
+    }
+    const double xd = (double)x;
+    double kd, r;
+    if constexpr (FMA) {
+        kd = __builtin_fma(INVLN2N, xd, SHIFT);
+    } else {
+        const double z = INVLN2N * xd;
+        kd = z + SHIFT;
+    }
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd -= SHIFT;
+    if constexpr (FMA) {
+        r = __builtin_fma(INVLN2N, xd, -kd);
+    } else {
+        const double z = INVLN2N * xd;
+        r = z - kd;
+    }
+    const uint64_t t = kExp2fTab[ki & 31u] + (ki << 47);
+    const double sc = __longlong_as_double((long long)t);
+    const double z2 = mad<FMA>(C0, r, C1);
+    const double r2 = r * r;
+    double y = mad<FMA>(C2, r, 1.0);
+    y = mad<FMA>(z2, r2, y);
+    y = y * sc;
+    return (float)y;
+}
+
+// ccexpf of reference src/complex.c:33-39 for ANY argument: the argument construction
+// `real + imag * I` followed by glibc 2.35 cexpf (math/s_cexp_template.c), on the two functions above.
+template <bool FMA>
+__device__ __forceinline__ void ccexpf_glibc(float re, float im, float &out_re, float &out_im)
+{
+    const float FLT_MIN_ = 1.17549435e-38f, FLT_MAX_ = 3.40282347e+38f;
+    const float inf = __uint_as_float(0x7f800000u), nan = __uint_as_float(0x7fc00000u);
+    float xr = __fadd_rn(re, __fmul_rn(im, 0.0f));
+    const float xi = im;
+    const bool r_fin = fabsf(xr) <= FLT_MAX_, i_fin = fabsf(xi) <= FLT_MAX_;     // false for inf and nan
+    float sinix = xi, cosix = 1.0f;
+    if (i_fin && fabsf(xi) > FLT_MIN_) sincosf_glibc<FMA>(xi, sinix, cosix);
+    if (r_fin) {
+        if (!i_fin) { out_re = out_im = nan; return; }
+        const float t = 88.0f;
+        if (xr > t) {
+            const float exp_t = expf_glibc<FMA>(t);
+            xr = __fsub_rn(xr, t);
+            sinix = __fmul_rn(sinix, exp_t);
+            cosix = __fmul_rn(cosix, exp_t);
+            if (xr > t) {
+                xr = __fsub_rn(xr, t);
+                sinix = __fmul_rn(sinix, exp_t);
+                cosix = __fmul_rn(cosix, exp_t);
+            }
+        }
+        if (xr > t) {
+            out_re = __fmul_rn(FLT_MAX_, cosix);
+            out_im = __fmul_rn(FLT_MAX_, sinix);
+        } else {
+            const float e = expf_glibc<FMA>(xr);
+            out_re = __fmul_rn(e, cosix);
+            out_im = __fmul_rn(e, sinix);
+        }
+    } else if (xr != xr) {                       // real part NaN
+        out_re = nan;
+        out_im = (xi == 0.0f) ? xi : nan;
+    } else if (i_fin) {                          // real part +-inf, imaginary finite
+        const float value = (__float_as_uint(xr) >> 31) ? 0.0f : inf;
+        if (xi == 0.0f) {
+            out_re = value;
+            out_im = xi;
+        } else {
+            out_re = copysignf(value, cosix);
+            out_im = copysignf(value, sinix);
+        }
+    } else if (!(__float_as_uint(xr) >> 31)) {   // +inf, imaginary inf/nan
+        out_re = inf;
+        out_im = xi - xi;
+    } else {                                     // -inf, imaginary inf/nan
+        out_re = 0.0f;
+        out_im = copysignf(0.0f, xi);
+    }
+}
+
+// The corrector of dsp.rs:121-122 for counter value n:
+//   theta = (-2*PI) * (ratio * (n as f32))   — each product rounded to f32,
+//   (c, s) = cexpf(0 + i*theta) = (cosf(theta), sinf(theta)).
+// ratio = shift_hz / (samplerate as f32) is rounded once on the host.
+template <bool FMA>
+__device__ __forceinline__ void corrector(float ratio, uint32_t n, float &c, float &s)
+{
+    const float p = __fmul_rn(ratio, (float)n);          // u32 -> f32 rounds to nearest even
+    const float theta = __fmul_rn(-6.28318530717958647692f, p);
+    sincosf_glibc<FMA>(theta, s, c);
+}
+
+// Four correctors at once (the four samples of a lane's 16-byte vector, or four blocks of a strided loop): the two f32
+// products are packed multiplies (each lane of a packed multiply rounds on its own, like the scalar one), ONE ballot
+// decides for all four whether the wavefront may take the fast path of sincosf_glibc, and the four polynomial chains
+// are independent instruction streams for the scheduler.  cs[k] = (cos, sin) for counter n[k].
+typedef float sc_f32x2 __attribute__((ext_vector_type(2)));
+template <bool FMA>
+__device__ __forceinline__ void corrector4(float ratio, const uint32_t n[4], sc_f32x2 cs[4])
+{
+    const sc_f32x2 r2 = {ratio, ratio}, m2 = {-6.28318530717958647692f, -6.28318530717958647692f};
+    const sc_f32x2 p01 = sc_f32x2{(float)n[0], (float)n[1]} * r2, p23 = sc_f32x2{(float)n[2], (float)n[3]} * r2;
+    const sc_f32x2 t01 = p01 * m2, t23 = p23 * m2;
+    const float th[4] = {t01.x, t01.y, t23.x, t23.y};
+    uint32_t lo = 0xffffffffu, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t a = __float_as_uint(th[k]) & 0x7fffffffu;
+        lo = a < lo ? a : lo;
+        hi = a > hi ? a : hi;
+    }
+    // every |theta| in [2^-12, 120)  (nan / inf have the largest magnitudes: they fail the upper bound)
+    const bool plain = lo >= 0x39800000u && hi < 0x42f00000u;
+    if (__builtin_amdgcn_ballot_w64(!plain) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t q;
+            float sn, c;
+            const double xr = reduce_small<FMA>((double)th[k], q);
+            sincos_poly<FMA>(xr, q, q, sn, c);
+            cs[k] = sc_f32x2{c, sn};
+        }
+    } else if (__builtin_amdgcn_ballot_w64(!(lo >= 0x42f00000u && hi < 0x50000000u)) == 0) {
+        // every |theta| in [120, 2^33)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t quad, sidx;
+            float sn, c;
+            const double xr = reduce_large<true>(__float_as_uint(th[k]), quad, sidx);
+            sincos_poly<FMA>(xr, quad, sidx, sn, c);
+            cs[k] = sc_f32x2{c, sn};
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float sn, c;
+            sincosf_general<FMA>(th[k], sn, c);
+            cs[k] = sc_f32x2{c, sn};
+        }
+    }
+}
+
+}  // namespace dpx

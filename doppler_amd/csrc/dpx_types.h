@@ -88,7 +88,8 @@ struct WalkSeg {           // one row chunk (kWalkWaves x kWalkRowsPerWave = 10 
     uint64_t A;            // first sample of the matrix (multiple of 32)
     uint64_t E;            // one past its last sample (multiple of 32)
     uint32_t L;            // row length in samples
-    uint32_t tab_off;      // table-pool entry index; entry x = corrector of column x - kWalkPad, 256 nw + kWalkPad entries
+    uint32_t tab_off;      // table-pool entry index; entry x = corrector of column x - kWalkPad, 256 nw + kWalkPad entries;
+                           // kWalkNoTable: the workgroups evaluate their slices themselves
     uint32_t wg_base;      // first workgroup of this chunk (multiple of 8); workgroup wg_base + w takes window w
     uint32_t nw;           // column windows per row
     uint32_t rows;         // rows of the matrix
@@ -96,7 +97,9 @@ struct WalkSeg {           // one row chunk (kWalkWaves x kWalkRowsPerWave = 10 
     uint32_t period;       // of the stretch (L is a multiple of it)
     uint32_t phase;        // counter of sample A, minus 1: column c uses counter ((phase + c) mod period) + 1
     float ratio;           // of the stretch (dsp.rs:121)
-    uint32_t pad[3];
+    uint32_t upw;          // rows per wavefront of this chunk (1..kWalkMaxRowsPerWave): wavefront v takes rows row0 + v * upw ...
+    uint32_t row_end;      // ... below row_end, one past the chunk's last row (<= row0 + waves * upw, <= rows)
+    uint32_t pad;
 };
 static_assert(sizeof(WalkSeg) == 64, "WalkSeg is read with scalar loads");
 
@@ -111,14 +114,16 @@ struct LeftRange {
 };
 static_assert(sizeof(LeftRange) == 24, "LeftRange is read with scalar loads");
 
+constexpr uint32_t kWalkNoTable = 0xffffffffu;
 constexpr uint32_t kWalkPad = 32;          // table entries before column 0 (the largest row shift is 31)
 constexpr uint32_t kWalkWindow = 256;      // samples per column window
 constexpr uint32_t kWalkMinL = 8192;       // shorter periods use a multiple as the row length
 constexpr int kWalkHintShift = 3;          // one WalkSeg index per 8 workgroups: exact, every chunk is padded to a multiple of 8
 constexpr int kLeftHintShift = 4;          // one LeftRange hint per 16 leftover workgroups
 constexpr uint32_t kLeftBlock = 1024;      // samples per leftover workgroup
-constexpr uint32_t kWalkWaves = 5;         // wavefronts per workgroup ...
-constexpr uint32_t kWalkRowsPerWave = 2;   // ... and rows per wavefront: 10 rows share one table slice
+constexpr uint32_t kWalkWaves = 6;         // wavefronts per workgroup ...
+constexpr uint32_t kWalkRowsPerWave = 2;   // ... and the most rows a wavefront takes by default (measured best; the kernel handles 1..4 per chunk)
+constexpr uint32_t kWalkMaxRowsPerWave = 4;
 constexpr uint32_t kWalkSlice = kWalkWindow + kWalkPad;   // table entries a window needs: 288
 constexpr uint32_t kWalkSinkBytes = 512 * 16;             // where lanes without a sample store
 
@@ -126,8 +131,8 @@ struct WalkArgs {
     uint32_t n_walk_wg;    // workgroups walking matrices
     uint32_t n_left_wg;    // workgroups evaluating leftover ranges
     uint32_t n_segs;
-    uint32_t waves, rows_per_wave;   // workgroup geometry the descriptors were laid out for
-    uint32_t compute_slice;          // 1: workgroups evaluate their 288 correctors themselves (no tables); 0: read them
+    uint32_t waves, rows_per_wave;   // workgroup geometry the descriptors were laid out for (rows_per_wave: the most a chunk may ask for)
+    uint32_t compute_slice;          // informational: 1 if any chunk evaluates its slices itself (WalkSeg::tab_off == kWalkNoTable)
 };
 
 struct TileArgs {
@@ -143,7 +148,7 @@ int launch_tiles(const void *d_in, int in_fmt, void *d_out, int out_fmt, const D
 int launch_rows(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,
                 const void *d_lut, const RowsArgs &r, bool fma, void *stream);
 int launch_walk(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs, const void *d_lut,
-                const WalkSeg *d_walk, const uint32_t *d_walk_hint, const LeftRange *d_left,
+                const WalkSeg *d_walk_desc /* one per 2^kWalkHintShift workgroups */, const LeftRange *d_left,
                 const uint32_t *d_left_hint, void *d_sink, const WalkArgs &w, bool fma, void *stream);
 int launch_build_lut(void *d_lut_entries, uint32_t period, uint32_t n_first, uint32_t n_entries,
                      float ratio, bool fma, void *stream);

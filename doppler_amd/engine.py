@@ -70,6 +70,11 @@ class Context:
         variant: 3 auto, 1 sincos per sample, 2 tabulated correctors. Applies to plans created afterwards."""
         check(self._lib.dpx_set_tuning(self._h, block, vecs, variant))
 
+    def set_options(self, **opts):
+        """Kernel-shape knobs (dpx_options: rows_mult, rows_maxl, rows_r, walk_waves, walk_rows, walk_compute,
+        walk_tilemin); no arguments restores the defaults. Applies to plans created afterwards."""
+        check(self._lib.dpx_set_options(self._h, _lib.make_options(opts)))
+
     def set_libm_contraction(self, fma=True):
         check(self._lib.dpx_set_libm_contraction(self._h, 1 if fma else 0))
 
@@ -245,7 +250,7 @@ def plan_describe(segments, samplerate, samplenum=0, variant=0):
     return res, fin.value
 
 
-def plan_simulate(segments, samplerate, samplenum=0, block=0, vecs=0, variant=3):
+def plan_simulate(segments, samplerate, samplenum=0, block=0, vecs=0, variant=3, options=None):
     """Host-only: per-sample counter values the launch list of a plan selects, and per-sample write
     counts (must all be 1). Returns (counters uint32[n], writes uint8[n]). Needs no GPU."""
     lib = _lib_handle()
@@ -259,11 +264,11 @@ def plan_simulate(segments, samplerate, samplenum=0, block=0, vecs=0, variant=3)
     counters = np.zeros(n, dtype=np.uint32)
     writes = np.zeros(n, dtype=np.uint8)
     check(lib.dpx_plan_simulate(arr, len(segs), int(samplerate), int(samplenum), block, vecs, variant,
-                                counters.ctypes.data, writes.ctypes.data, n))
+                                _lib.make_options(options), counters.ctypes.data, writes.ctypes.data, n))
     return counters, writes
 
 
-def plan_layout(segments, samplerate, samplenum=0, block=0, vecs=0, variant=3):
+def plan_layout(segments, samplerate, samplenum=0, block=0, vecs=0, variant=3, options=None):
     """Host-only: how a plan is laid out over the kernels (dict of the dpx_layout fields). Needs no GPU."""
     lib = _lib_handle()
     segs = list(segments)
@@ -272,7 +277,8 @@ def plan_layout(segments, samplerate, samplenum=0, block=0, vecs=0, variant=3):
         arr[i].n_samples = int(cnt)
         arr[i].shift_hz = float(hz)
     lay = _lib.Layout()
-    check(lib.dpx_plan_layout(arr, len(segs), int(samplerate), int(samplenum), block, vecs, variant, C.byref(lay)))
+    check(lib.dpx_plan_layout(arr, len(segs), int(samplerate), int(samplenum), block, vecs, variant,
+                              _lib.make_options(options), C.byref(lay)))
     return {name: getattr(lay, name) for name, _ in _lib.Layout._fields_}
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DPX_ABI_VERSION 1
+#define DPX_ABI_VERSION 2
 
 /* reference src/usage.rs:39-42  enum DataType { F32, I16 } */
 #define DPX_FMT_I16 0
@@ -105,6 +105,23 @@ int dpx_ccexpf(dpx_ctx *ctx, dpx_complex32 *z, size_t n);
  * z[k] <- cexpf(0 + i*z[k].im); z[k].re is ignored. */
 int dpx_ccexpf_imag(dpx_ctx *ctx, dpx_complex32 *z, size_t n);
 
+/* Kernel-shape knobs for measurements (all 0 / -1 = the planner's own choice).  They never change a result,
+ * only which launch shape produces it; profiles/ names the values behind every alternative it reports. */
+typedef struct dpx_options {
+    uint32_t rows_mult;      /* rows kernel: row length = rows_mult * lcm(period, 4) samples */
+    uint32_t rows_maxl;      /* rows kernel: longest row considered */
+    uint32_t rows_r;         /* rows kernel: rows per wavefront (2, 4 or 8) */
+    uint32_t walk_waves;     /* walk kernel: wavefronts per workgroup (4, 5, 6 or 8) */
+    uint32_t walk_rows;      /* walk kernel: most rows per wavefront a chunk may use (1..4) */
+    int32_t walk_compute;    /* walk kernel: 1 = workgroups always evaluate their corrector slices, 0 = always plan-time tables,
+                              * -1 = per matrix (tables for matrices of at least walk_table_rows rows) */
+    uint32_t walk_table_rows; /* that threshold */
+    uint32_t reserved;
+    uint64_t walk_tilemin;   /* walk plans: uncovered gaps at least this long (samples) get a tile-kernel launch */
+} dpx_options;
+/* applies to plans created afterwards; NULL restores the defaults */
+int dpx_set_options(dpx_ctx *ctx, const dpx_options *opt);
+
 /* ------------------------------------------------- host-side counter algebra
  * Closed form of the counter rule dsp.rs:125-130 (pure host integer/f32 code). */
 
@@ -118,8 +135,9 @@ int dpx_samplenum_after(float shift_hz, uint32_t samplerate, uint32_t samplenum0
 
 /* One stretch of the stream in which the counter is a closed form of the
  * sample index j (relative to `first`):  period == 0: n = n_start + j;
- * period > 0: n = ((n_start - 1 + j) mod period) + 1.  lut_len > 0: the kernel
- * keeps one period of correctors in LDS for this stretch. */
+ * period > 0: n = ((n_start - 1 + j) mod period) + 1.  lut_len > 0: one period of
+ * correctors is tabulated in device memory at plan time for this stretch
+ * (lut_len == 0: the kernels evaluate sincos themselves). */
 typedef struct {
     uint64_t first, count;
     float ratio;
@@ -137,7 +155,7 @@ int dpx_plan_describe(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
  * how many launches write it (writes[n_samples], must be exactly 1 everywhere).
  * block / vecs / variant as in dpx_set_tuning (0 = defaults). */
 int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
-                      uint32_t samplenum0, int block, int vecs, int variant,
+                      uint32_t samplenum0, int block, int vecs, int variant, const struct dpx_options *opt,
                       uint32_t *counters, uint8_t *writes, uint64_t n_samples);
 
 /* Host-only: how the planner lays a segment list out over the kernels (what dpx_run_device will launch). */
@@ -153,7 +171,7 @@ typedef struct dpx_layout {
     uint32_t walk_matrices, walk_workgroups, leftover_ranges, leftover_workgroups;
 } dpx_layout;
 int dpx_plan_layout(const dpx_segment *segs, size_t n_segs, uint32_t samplerate, uint32_t samplenum0,
-                    int block, int vecs, int variant, dpx_layout *out);
+                    int block, int vecs, int variant, const struct dpx_options *opt, dpx_layout *out);
 
 /* ------------------------------------------------ track mode, host side (N2)
  * Host-only.  The per-block shift schedule of `doppler track --time` (reference

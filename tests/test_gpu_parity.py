@@ -339,18 +339,46 @@ def test_walk_kernel_plans_vs_oracle(ctx, orc, intype, outtype):
     assert_same_bytes(got, want, outtype, "forced walk %s->%s" % (intype, outtype))
 
 
-def test_walk_kernel_on_the_fly_slices():
-    """DPX_WALK_COMPUTE=1 (read once per process): the walk kernel's workgroups evaluate their corrector slices
-    themselves instead of reading plan-time tables.  Same parity bar; run in a child process."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DPX_WALK_COMPUTE="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
-                        "-k", "walk_kernel_plans_vs_oracle or walk_kernel_random_plans"], cwd=root, env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
+@pytest.mark.parametrize("compute", [0, 1])
+@pytest.mark.parametrize("waves,max_rows", [(4, 4), (5, 4), (6, 4), (8, 4), (5, 1), (5, 2), (5, 3), (8, 2)])
+def test_walk_kernel_workgroup_shapes_and_on_the_fly_slices(ctx, orc, waves, max_rows, compute):
+    """Every workgroup shape of the walk kernel, with plan-time tables (compute=0) and with the workgroups evaluating
+    their corrector slices themselves (compute=1), with chunks of 1..4 rows per wavefront, on matrices whose row counts
+    leave 1..waves-1 wavefronts of a chunk without rows (those wavefronts end before the workgroup's barrier), all
+    format pairs."""
+    import doppler_amd
+    rate = 256000
+    # periods 8192..40000 at this rate: rows = count / period takes many residues modulo 2 * waves
+    segs = [(rate + 2048 * k, float(np.float32(-3000.0 + 517.3 * k))) for k in range(9)] + [(5 * rate // 2, 1000.0), (3 * rate, 7.0)]
+    n = sum(c for c, _ in segs)
+    opts = dict(walk_waves=waves, walk_rows=max_rows, walk_compute=compute)
+    lay = doppler_amd.plan_layout(segs, rate, variant=5, options=opts)
+    assert lay["walk_launches"] == 1 and lay["walk_matrices"] >= 9 and lay["rows_launches"] == 0, lay
+    assert lay["table_entries"] == 0 or not compute
+    ctx.set_tuning(0, 0, 5)
+    ctx.set_options(**opts)
+    try:
+        for intype, outtype in (("i16", "i16"), ("f32", "i16"), ("i16", "f32"), ("f32", "f32")):
+            x = make_iq(intype, n, 1300 + waves, full_scale=True)
+            want, sn = orc.segments_stream(x, intype, outtype, segs, rate, threads=16)
+            got, fin = run_bulk(ctx, x, intype, outtype, segs, rate)
+            assert fin == sn
+            assert_same_bytes(got, want, outtype, "walk %d waves x <=%d rows, compute=%d, %s->%s" % (waves, max_rows, compute, intype, outtype))
+    finally:
+        ctx.set_options()
+        ctx.set_tuning(0, 0, 3)
+
+
+def test_walk_kernel_plans_with_on_the_fly_slices(ctx, orc):
+    """The plan shapes of test_walk_kernel_plans_vs_oracle and test_walk_kernel_random_plans again with walk_compute=1
+    (no corrector tables at all)."""
+    ctx.set_options(walk_compute=1)
+    try:
+        for pair in (("i16", "i16"), ("f32", "i16")):
+            test_walk_kernel_plans_vs_oracle(ctx, orc, *pair)
+        test_walk_kernel_random_plans(ctx, orc)
+    finally:
+        ctx.set_options()
 
 
 def test_walk_kernel_random_plans(ctx, orc):

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert set(declared) == set(_lib._SIGNATURES), set(declared) ^ set(_lib._SIGNATURES)
-    assert doppler_amd.lib.dpx_abi_version() == 1
+    assert doppler_amd.lib.dpx_abi_version() == 2
 
 
 def test_no_cpu_fallback_anywhere():
@@ -127,6 +127,14 @@ def test_walk_kernel_plans(orc):
             c, w = doppler_amd.plan_simulate(segs, rate, sn0, 128, 2, variant)
             assert (w == 1).all(), (segs[:3], variant, np.flatnonzero(w != 1)[:5], w[np.flatnonzero(w != 1)[:5]])
             assert np.array_equal(c, want), (segs[:3], variant, np.flatnonzero(c != want)[:5])
+        # the measurement knobs (dpx_options) change the launch shapes, never the counters
+        for opts in (dict(walk_compute=1), dict(walk_compute=0), dict(walk_table_rows=3), dict(walk_waves=4), dict(walk_waves=8, walk_compute=1), dict(walk_waves=6, walk_tilemin=1000),
+                     dict(rows_r=4, rows_mult=3), dict(walk_rows=1), dict(walk_rows=2, walk_waves=4), dict(walk_rows=3, walk_compute=1)):
+            c, w = doppler_amd.plan_simulate(segs, rate, sn0, 128, 2, 3, options=opts)
+            assert (w == 1).all() and np.array_equal(c, want), (i, opts)
+            if "walk_compute" in opts and i < 3:    # tables for every matrix / for none
+                te = doppler_amd.plan_layout(segs, rate, sn0, 128, 2, 3, options=opts)["table_entries"]
+                assert (te == 0) == bool(opts["walk_compute"]), (i, opts, te)
 
 
 def test_header_is_plain_c(tmp_path):
@@ -138,7 +146,7 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "doppler_hip.h"\n#include <stdio.h>\n'
                    'int main(void) { dpx_layout l; dpx_segment s = {2048, 5000.0f}; dpx_stretch st[4]; size_t n = 0; uint32_t fin = 0;\n'
                    '  if (dpx_plan_describe(&s, 1, 1024000, 0, 3, st, 4, &n, &fin) != DPX_OK) return 2;\n'
-                   '  if (dpx_plan_layout(&s, 1, 1024000, 0, 0, 0, 3, &l) != DPX_OK) return 3;\n'
+                   '  if (dpx_plan_layout(&s, 1, 1024000, 0, 0, 0, 3, NULL, &l) != DPX_OK) return 3;\n'
                    '  printf("%d %u %llu\\n", dpx_abi_version(), fin, (unsigned long long)l.n_samples); return 0; }\n')
     exe = tmp_path / "hdr"
     lib = os.path.join(root, "doppler_amd", "lib")

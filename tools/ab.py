@@ -1,0 +1,174 @@
+"""A/B measurement of kernel shapes on one MI355X (development tool, not the bench contract).
+
+    python tools/ab.py [--rounds R] [--iters K] [--only SUBSTR] [--set NAME]
+
+Every case = (workload, format pair, dpx_set_tuning variant, dpx_options).  All plans are built first, then the cases are
+timed round-robin (R rounds x K back-to-back launches each, one HIP event pair per burst) so that clock and thermal
+drift hit every case alike; the median burst is reported as algorithmic GB/s and % of the 8 TB/s HBM peak.
+"""
+import argparse
+import calendar
+import json
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import doppler_amd  # noqa: E402
+
+BPS = {"i16": 4, "f32": 8}
+RATE = 1024000
+
+
+def track_segs(seconds, fmt):
+    start = calendar.timegm((2015, 1, 22, 19, 48, 0)) if seconds <= 600 else calendar.timegm((2015, 1, 22, 19, 23, 0))
+    return bench.track_segments(seconds, RATE, fmt, start)
+
+
+def const_segs(shift, n=268435456):
+    return [(n, float(shift))]
+
+
+def synth_segs(rows, total=614400000, P=65536):
+    """stretches of exactly `rows` periods of P = 65536 (shift = odd multiples of rate / 65536)"""
+    segs, m, left = [], 1, total
+    while left > 0:
+        cnt = min(left, rows * P)
+        segs.append((cnt, RATE / 65536.0 * (m % 256)))   # m odd <= 255: m * n < 2^24 is exact in f32, so P = 65536 exactly
+        m += 2
+        left -= cnt
+    return segs
+
+
+def cases(which):
+    c = []
+    if which in ("synth",):
+        c.append(("synth one matrix of P=65536", lambda f: [(614400000, RATE / 65536.0)], "i16:i16", 5, dict(walk_compute=0)))
+        c.append(("synth one matrix of P=65536", lambda f: [(614400000, RATE / 65536.0)], "i16:i16", 5, dict(walk_compute=1)))
+        for rows in (2, 3, 4, 5, 6, 8, 10, 13, 16, 20, 26, 40):
+            for comp in (0, 1):
+                for waves in (5,):
+                    c.append(("synth %d rows of P=65536" % rows, lambda f, r=rows: synth_segs(r), "i16:i16", 3, dict(walk_compute=comp, walk_waves=waves)))
+    if which == "size":
+        for n in (268435456, 614400000, 1073741824):
+            c.append(("const 5000 Hz n=%d" % n, lambda f, n=n: const_segs(5000, n), "i16:i16", 3, {}))
+            c.append(("const 5001 Hz n=%d" % n, lambda f, n=n: const_segs(5001, n), "i16:i16", 3, dict(walk_compute=1)))
+        for secs in (150, 262, 600):
+            for comp in (0, 1):
+                c.append(("track %d s replay" % secs, lambda f, t=secs: track_segs(t, f), "i16:i16", 3, dict(walk_compute=comp)))
+    if which == "final":
+        for opts in (dict(), dict(walk_waves=5), dict(walk_waves=8), dict(walk_compute=0)):
+            c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, opts))
+            c.append(("track 300 s replay", lambda f: track_segs(300, f), "f32:i16", 3, opts))
+        for rows in (2, 3, 4, 6, 8, 12):
+            c.append(("synth %d rows of P=65536" % rows, lambda f, r=rows: synth_segs(r), "i16:i16", 3, dict()))
+        for shift in (5001, 777):
+            for opts in (dict(), dict(walk_waves=5), dict(walk_compute=0)):
+                c.append(("const %d Hz" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 3, opts))
+    if which == "hybrid":
+        for opts in (dict(walk_compute=1), dict(walk_compute=0), dict(), dict(walk_table_rows=12), dict(walk_table_rows=16), dict(walk_table_rows=32),
+                     dict(walk_table_rows=48), dict(walk_waves=8), dict(walk_waves=6), dict(walk_waves=8, walk_table_rows=16)):
+            c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, opts))
+        for opts in (dict(walk_compute=1), dict(walk_compute=0), dict(), dict(walk_table_rows=16), dict(walk_waves=8), dict(walk_waves=6)):
+            c.append(("track 300 s replay", lambda f: track_segs(300, f), "f32:i16", 3, opts))
+        for opts in (dict(walk_compute=1), dict()):
+            c.append(("const 5001 Hz", lambda f: const_segs(5001), "i16:i16", 3, opts))
+    if which == "shape":
+        for waves, rows in ((5, 2), (8, 2), (8, 3), (10, 2), (12, 2), (16, 2), (6, 2), (10, 1), (16, 1)):
+            c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, dict(walk_compute=1, walk_waves=waves, walk_rows=rows)))
+        for waves, rows in ((5, 2), (8, 2), (12, 2)):
+            c.append(("track 300 s replay", lambda f: track_segs(300, f), "f32:i16", 3, dict(walk_compute=1, walk_waves=waves, walk_rows=rows)))
+            c.append(("const 5001 Hz", lambda f: const_segs(5001), "i16:i16", 3, dict(walk_compute=0, walk_waves=waves, walk_rows=rows)))
+    if which in ("walk", "all"):
+        for comp in (0, 1):
+            c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, dict(walk_compute=comp)))
+        for comp in (0, 1):
+            c.append(("track 300 s replay", lambda f: track_segs(300, f), "f32:i16", 3, dict(walk_compute=comp)))
+        for waves, rows in ((5, 2), (5, 3), (4, 4), (6, 4), (8, 4), (8, 2)):
+            for comp in (0, 1):
+                c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, dict(walk_compute=comp, walk_waves=waves, walk_rows=rows)))
+    if which in ("const", "all"):
+        for shift in (5001, 9999, 777, 1234):
+            for comp in (0, 1):
+                c.append(("const %d Hz" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 3, dict(walk_compute=comp)))
+        for shift in (3, 100):
+            c.append(("const %d Hz" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 3, {}))
+            for comp in (0, 1):
+                c.append(("const %d Hz (walk forced)" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 5, dict(walk_compute=comp)))
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+    if which in ("persample", "all"):
+        for shift in (3, 5001):
+            for pair in ("i16:i16", "f32:f32"):
+                for geom in ((128, 2), (256, 1)):
+                    c.append(("const %d Hz, sincos per sample" % shift, lambda f, s=shift: const_segs(s), pair, 1, dict(_geom=geom)))
+    return c
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final"])
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    ctx = doppler_amd.Context(0)
+    stream = torch.cuda.current_stream()
+    bufs = {}
+    built = []
+    seg_cache = {}
+    for name, mk, pair, variant, opts in cases(args.set):
+        if args.only and args.only not in name:
+            continue
+        it, ot = pair.split(":")
+        key = (name.split(" (")[0].split(",")[0].replace("5001 Hz n", "5001 Hz  n"), it)
+        if key not in seg_cache:
+            seg_cache[key] = mk(it)
+        segs = seg_cache[key]
+        n = sum(c for c, _ in segs)
+        opts = dict(opts)
+        block, vecs = opts.pop("_geom", (128, 2))
+        ctx.set_tuning(block, vecs, variant)
+        ctx.set_options(**opts)
+        plan = ctx.plan_segments(segs, RATE)
+        lay = doppler_amd.plan_layout(segs, RATE, 0, block, vecs, variant, options=opts)
+        if (it, "in", n) not in bufs:
+            bufs[(it, "in", n)] = (torch.randint(-23170, 23171, (2 * n,), dtype=torch.int16, device=dev) if it == "i16"
+                                   else torch.rand(2 * n, dtype=torch.float32, device=dev) * 2 - 1)
+        if (ot, "out", n) not in bufs:
+            bufs[(ot, "out", n)] = torch.empty(n * BPS[ot], dtype=torch.uint8, device=dev)
+        built.append(dict(name=name, pair=pair, variant=variant, opts=opts, geom=(block, vecs), plan=plan, n=n, it=it, ot=ot, lay=lay, ms=[]))
+    ctx.set_tuning(128, 2, 3)
+    ctx.set_options()
+    for b in built:        # warm-up
+        x, o = bufs[(b["it"], "in", b["n"])], bufs[(b["ot"], "out", b["n"])]
+        for _ in range(3):
+            b["plan"].run(x.data_ptr(), b["it"], o.data_ptr(), b["ot"], stream.cuda_stream)
+    stream.synchronize()
+    for _ in range(args.rounds):
+        for b in built:
+            x, o = bufs[(b["it"], "in", b["n"])], bufs[(b["ot"], "out", b["n"])]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(args.iters):
+                b["plan"].run(x.data_ptr(), b["it"], o.data_ptr(), b["ot"], stream.cuda_stream)
+            e1.record(stream)
+            stream.synchronize()
+            b["ms"].append(e0.elapsed_time(e1) / args.iters)
+    for b in built:
+        med = statistics.median(b["ms"])
+        alg = b["n"] * (BPS[b["it"]] + BPS[b["ot"]])
+        gbs = alg / med / 1e6
+        lay = b["lay"]
+        kern = "walk" if lay["walk_launches"] else ("rows" if lay["rows_launches"] else "tile")
+        print(json.dumps({"case": b["name"], "pair": b["pair"], "variant": b["variant"], "opts": b["opts"], "geom": b["geom"], "kernel": kern,
+                          "ms_med": round(med, 4), "ms_min": round(min(b["ms"]), 4), "GBps": round(gbs, 1), "pct_peak": round(gbs / 80, 1),
+                          "table_MiB": round(lay["table_entries"] * 8 / 2**20, 1), "single_samples": lay["single_samples"]}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
