@@ -29,7 +29,7 @@ $(LIBDIR)/dpx_api.o: $(CSRC)/dpx_api.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types
 
 $(LIBDIR)/dpx_planner.o: $(CSRC)/dpx_planner.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h
 	@mkdir -p $(LIBDIR)
-	g++ -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -c $< -o $@
+	g++ -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -c $< -o $@
 
 $(LIBDIR)/%.o: $(CSRC)/host/%.cpp $(CSRC)/host/orbit.h $(CSRC)/host/schedule.h
 	@mkdir -p $(LIBDIR)

@@ -91,6 +91,7 @@ _SIGNATURES = {
     "dpx_plan_final_samplenum": (_i, [_vp, _P(_u32)]),
     "dpx_plan_destroy": (None, [_vp]),
     "dpx_stream_create": (_i, [_vp, _i, _i, _u32, _u32, _sz, _i, _P(_vp)]),
+    "dpx_stream_create_multi": (_i, [_P(_vp), _i, _i, _i, _u32, _u32, _sz, _i, _P(_vp)]),
     "dpx_stream_acquire": (_i, [_vp, _P(_vp), _P(_sz)]),
     "dpx_stream_submit": (_i, [_vp, _sz, _P(Segment), _sz]),
     "dpx_stream_pending": (_i, [_vp, _P(_i)]),

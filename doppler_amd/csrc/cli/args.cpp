@@ -65,6 +65,8 @@ const Flag kConstFlags[] = {
     {"INTYPE", "intype", 'i', true, true, "IQ data input type"},
     {"OUTTYPE", "outtype", 'o', false, true, "IQ data output type"},
     {"SHIFT", "shift", 0, true, false, "frequency shift in Hz"},
+    // extension of this build (the reference has no such flag): see args.h
+    {"GPUS", "gpus", 0, false, false, "[extension] number of GPUs to spread the stream over (default 1, or $DOPPLER_GPUS)"},
 };
 const Flag kTrackFlags[] = {
     {"SAMPLERATE", "samplerate", 's', true, false, "IQ data samplerate"},
@@ -78,6 +80,7 @@ const Flag kTrackFlags[] = {
     {"OFFSET", "offset", 0, false, false, "Constant frequency shift in Hz. Can be used to compensate constant offset"},
     // extension of this build (the reference has no such flag): see args.h
     {"RANGERATEFILE", "range-rate-file", 0, false, false, "[extension] text file with one range rate (km/s) per whole second; replaces --tlefile/--tlename/--location"},
+    {"GPUS", "gpus", 0, false, false, "[extension] number of GPUs to spread the stream over (default 1, or $DOPPLER_GPUS)"},
 };
 
 void usage(FILE *f, const char *sub, const Flag *flags, size_t n)
@@ -186,6 +189,7 @@ int parse_args(int argc, char **argv, CommandArgs *out, bool *exit_now)
         return clap_error("Invalid value: The argument '%s' isn't a valid value", val[name]);   // value_t_or_exit!
     };
     if (!parse_int<uint32_t>(val["SAMPLERATE"], &out->samplerate)) return bad("SAMPLERATE");
+    if (val.count("GPUS") && (!parse_int<uint32_t>(val["GPUS"], &out->gpus) || out->gpus < 1 || out->gpus > 64)) return bad("GPUS");
     out->inputtype = val["INTYPE"] == "f32" ? DataType::F32 : DataType::I16;
     out->outputtype = val.count("OUTTYPE") ? (val["OUTTYPE"] == "f32" ? DataType::F32 : DataType::I16) : out->inputtype;
     if (out->mode == Mode::Const) {

@@ -35,6 +35,8 @@ struct CommandArgs {                       // usage.rs:61-83
     int32_t offset = 0;
     // extension (not in the reference): whole-second range-rate table instead of TLE propagation
     std::string range_rate_file;
+    // extension (not in the reference): GPUs to spread the stream over; 0 = not given (1, or $DOPPLER_GPUS)
+    uint32_t gpus = 0;
 };
 
 // usage.rs:85-115 parse_location: "lat=58.64560,lon=23.15163,alt=8"

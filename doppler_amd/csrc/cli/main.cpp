@@ -5,24 +5,36 @@
 //   * the loop ends with the first short (possibly empty) read (main.rs:98,115-117);
 //   * a final block that is not a whole number of samples aborts before producing output for that
 //     block (the reference's assert!, dsp.rs:87/103) — exit status 101 like a Rust panic;
-//   * the sample counter `samplenr` (main.rs:60) is carried through the whole run.
-// What changes is the granularity of the work: blocks are gathered into slabs (as many complete
-// blocks as are available without waiting, up to DOPPLER_SLAB_BYTES), each slab is one plan + one
-// fused launch, and three slabs rotate (the dpx_stream_* ring of the C ABI) so that reading, PCIe
-// copies, the kernel and writing overlap.
-// A live 1 Msps pipe therefore still moves in ~8-64 KiB steps, a file at PCIe speed.
+//   * the sample counter `samplenr` (main.rs:60) is carried through the whole run;
+//   * a failed read or write is a panic in the reference (`expect` / `unwrap`, main.rs:63,86-95): status 101.
+// What changes is the granularity of the work: blocks are gathered into slabs, each slab is one plan + one fused
+// launch, and a ring of slabs rotates (the dpx_stream_* ring of the C ABI) so that reading, PCIe copies in both
+// directions, the kernels and writing overlap.  Three shapes of I/O:
+//   * a pipe or terminal on stdin: ONE reader takes as many complete blocks as are available without waiting, up to
+//     DOPPLER_SLAB_BYTES — a live 1 Msps pipe still moves in ~8-64 KiB steps, a fast producer in whole slabs;
+//   * a regular file on stdin: the slabs are filled in parallel by DOPPLER_IO_THREADS workers with pread() at the
+//     offsets the sequential loop would have reached (a single read() stream is what bounded round 1 at 1.4 Gsamples/s);
+//   * a regular file on stdout: drained the same way with pwrite(); a pipe gets one ordered writer.
+// With --gpus N (extension) the ring spans N GPUs: slab k runs on GPU k mod N (dpx_stream_create_multi) — the slabs ARE
+// the time chunks of the sharded design, the counter is carried on the host, every GPU copies its own output back.
+// Live track mode (no --time) evaluates the orbit once per 8192-byte block, like the reference (main.rs:186-205): its
+// slabs are a single block.
 #include <errno.h>
+#include <fcntl.h>
 #include <poll.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <sys/time.h>
 #include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <fstream>
 #include <functional>
 #include <memory>
@@ -39,6 +51,7 @@
 namespace {
 
 // fern format of the reference (main.rs:220-223): "{ts}.{ms:3} [{level:<6} {module:<30} {line:>3}]  {msg}"
+std::mutex g_log_mu;
 void info(const char *fmt, ...)
 {
     struct timeval tv;
@@ -47,6 +60,7 @@ void info(const char *fmt, ...)
     localtime_r(&tv.tv_sec, &tmv);
     char ts[32];
     strftime(ts, sizeof(ts), "%Y-%m-%dT%H:%M:%S", &tmv);
+    std::lock_guard<std::mutex> lk(g_log_mu);
     fprintf(stderr, "%s.%3d [%-6s %-30s %3d]  ", ts, (int)(tv.tv_usec / 1000), "INFO", "doppler", 0);
     va_list ap;
     va_start(ap, fmt);
@@ -55,32 +69,31 @@ void info(const char *fmt, ...)
     fputc('\n', stderr);
 }
 
-#define DPXCHK(call)                                                                     \
-    do {                                                                                 \
-        int rc_ = (call);                                                                \
-        if (rc_ != DPX_OK) {                                                             \
-            fprintf(stderr, "doppler: %s failed (%d): %s\n", #call, rc_, dpx_last_error()); \
-            exit(1);                                                                     \
-        }                                                                                \
-    } while (0)
-
-bool write_all(int fd, const char *p, size_t n)
+// Wall clock of live track mode.  DOPPLER_FAKE_CLOCK=<unix seconds>,<seconds per call> (tests only) replaces it with a
+// clock that advances by a fixed step per query, which makes the per-block cadence of main.rs:186-205 observable.
+double wall_clock()
 {
-    while (n) {
-        const ssize_t w = write(fd, p, n);
-        if (w < 0) {
-            if (errno == EINTR) continue;
-            return false;
+    static const char *fake = getenv("DOPPLER_FAKE_CLOCK");
+    if (fake) {
+        static double t0 = 0, step = 0, t = 0;
+        static bool init = false;
+        if (!init) {
+            sscanf(fake, "%lf,%lf", &t0, &step);
+            t = t0;
+            init = true;
+        } else {
+            t += step;
         }
-        p += w;
-        n -= (size_t)w;
+        return t;
     }
-    return true;
+    struct timeval tv;
+    gettimeofday(&tv, nullptr);
+    return tv.tv_sec + tv.tv_usec * 1e-6;
 }
 
-// Blocks until at least one full 8192-byte block or EOF, then keeps taking what is already
-// there (never waits for more) up to `cap`.  Returns bytes read; *eof set at end of input.
-size_t gather(int fd, char *buf, size_t cap, bool *eof)
+// Reads into buf until at least one full 8192-byte block or EOF, then keeps taking what is already there (never waits
+// for more) up to `cap`.  Returns bytes read, or -1 on a read error; *eof set at end of input.
+ssize_t gather(int fd, char *buf, size_t cap, bool *eof)
 {
     size_t n = 0;
     while (n < cap) {
@@ -91,8 +104,7 @@ size_t gather(int fd, char *buf, size_t cap, bool *eof)
         const ssize_t r = read(fd, buf + n, cap - n);
         if (r < 0) {
             if (errno == EINTR) continue;
-            fprintf(stderr, "doppler collect error\n");    // main.rs:63
-            exit(101);
+            return -1;
         }
         if (r == 0) {
             *eof = true;
@@ -100,8 +112,87 @@ size_t gather(int fd, char *buf, size_t cap, bool *eof)
         }
         n += (size_t)r;
     }
-    return n;
+    return (ssize_t)n;
 }
+
+bool pread_all(int fd, char *buf, size_t n, off_t off)
+{
+    while (n) {
+        const ssize_t r = pread(fd, buf, n, off);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        if (r == 0) return false;       // the file shrank under us
+        buf += r;
+        off += r;
+        n -= (size_t)r;
+    }
+    return true;
+}
+
+bool write_all(int fd, const char *p, size_t n, bool positioned, off_t off)
+{
+    while (n) {
+        const ssize_t w = positioned ? pwrite(fd, p, n, off) : write(fd, p, n);
+        if (w < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        p += w;
+        off += w;
+        n -= (size_t)w;
+    }
+    return true;
+}
+
+// a tiny pool: jobs run on `n` threads, in any order
+class Workers {
+public:
+    explicit Workers(int n)
+    {
+        for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
+    }
+    ~Workers() { stop(); }
+    void push(std::function<void()> job)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            q_.push_back(std::move(job));
+        }
+        cv_.notify_one();
+    }
+    void stop()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            done_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread &t : th_) if (t.joinable()) t.join();
+    }
+
+private:
+    void run()
+    {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return done_ || !q_.empty(); });
+                if (q_.empty()) return;
+                job = std::move(q_.front());
+                q_.pop_front();
+            }
+            job();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> q_;
+    std::vector<std::thread> th_;
+    bool done_ = false;
+};
 
 }  // namespace
 
@@ -114,7 +205,7 @@ int main(int argc, char **argv)
 
     const int in_fmt = args.inputtype == dpx::DataType::I16 ? DPX_FMT_I16 : DPX_FMT_F32;
     const int out_fmt = args.outputtype == dpx::DataType::I16 ? DPX_FMT_I16 : DPX_FMT_F32;
-    const size_t ibs = in_fmt == DPX_FMT_I16 ? 4 : 8;
+    const size_t ibs = in_fmt == DPX_FMT_I16 ? 4 : 8, obs = out_fmt == DPX_FMT_I16 ? 4 : 8;
 
     info("doppler %s (MI355X hot path)\n\n", "1.1.10");
     std::function<double(int64_t)> range_rate;      // replay: seconds since --time
@@ -176,53 +267,142 @@ int main(int argc, char **argv)
         info("\toffset          : %d Hz\n\n\n", args.has_offset ? args.offset : 0);
     }
 
-    dpx_ctx *ctx = nullptr;
-    if (dpx_ctx_create(0, &ctx) != DPX_OK) {
-        fprintf(stderr, "doppler: %s\n", dpx_last_error());
-        return 1;
+    // ---- GPUs: --gpus N / DOPPLER_GPUS (devices 0..N-1), or an explicit list in DOPPLER_DEVICES (a device may repeat:
+    // separate contexts on it — how the multi-GPU path is exercised on a one-GPU box)
+    std::vector<int> devices;
+    if (const char *e = getenv("DOPPLER_DEVICES")) {
+        for (const char *p = e; *p;) {
+            devices.push_back((int)strtol(p, const_cast<char **>(&p), 10));
+            while (*p == ',' || *p == ' ') ++p;
+        }
     }
+    uint32_t n_gpus = args.gpus;
+    if (n_gpus == 0) {
+        const char *e = getenv("DOPPLER_GPUS");
+        n_gpus = e ? (uint32_t)atoi(e) : (devices.empty() ? 1u : (uint32_t)devices.size());
+    }
+    if (n_gpus < 1 || n_gpus > 64) n_gpus = 1;
+    if (devices.empty()) for (uint32_t i = 0; i < n_gpus; ++i) devices.push_back((int)i);
+    devices.resize(n_gpus, devices.back());
+    std::vector<dpx_ctx *> ctxs;
+    auto destroy_ctxs = [&] { for (dpx_ctx *c : ctxs) dpx_ctx_destroy(c); };
+    for (int d : devices) {
+        dpx_ctx *c = nullptr;
+        if (dpx_ctx_create(d, &c) != DPX_OK) {
+            fprintf(stderr, "doppler: %s\n", dpx_last_error());
+            destroy_ctxs();
+            return 1;
+        }
+        ctxs.push_back(c);
+    }
+    if (n_gpus > 1) info("\tGPUs            : %u", n_gpus);
 
+    const bool replay = args.mode == dpx::Mode::Track && args.has_time;
+    const bool live_track = args.mode == dpx::Mode::Track && !args.has_time;
     size_t slab_bytes = 8u << 20;       // measured on the GPU box: 4-8 MiB slabs beat larger ones end to end
     if (const char *e = getenv("DOPPLER_SLAB_BYTES")) slab_bytes = strtoull(e, nullptr, 0);
     slab_bytes = (slab_bytes / DPX_BUFFER_SIZE) * DPX_BUFFER_SIZE;
     if (slab_bytes < DPX_BUFFER_SIZE) slab_bytes = DPX_BUFFER_SIZE;
+    if (live_track) slab_bytes = DPX_BUFFER_SIZE;          // main.rs:186-205: predict.update() before every block
 
-    // three pinned slabs in rotation (include/doppler_hip.h, "streaming from host memory")
+    struct stat sin, sout;
+    const bool in_file = fstat(STDIN_FILENO, &sin) == 0 && S_ISREG(sin.st_mode) && !live_track && !getenv("DOPPLER_NO_PREAD");
+    // (an O_APPEND descriptor ignores pwrite offsets: it gets the single ordered writer)
+    const bool out_file = fstat(STDOUT_FILENO, &sout) == 0 && S_ISREG(sout.st_mode) && !(fcntl(STDOUT_FILENO, F_GETFL) & O_APPEND) &&
+                          !getenv("DOPPLER_NO_PWRITE");
+    int io_threads = 4;
+    if (const char *e = getenv("DOPPLER_IO_THREADS")) io_threads = std::max(1, std::min(64, atoi(e)));
+    const int slabs_per_gpu = in_file || out_file ? std::max(3, (2 * io_threads + (int)n_gpus - 1) / (int)n_gpus + 1) : 3;
+    const int n_slabs = slabs_per_gpu * (int)n_gpus;
+
     dpx_stream *stream = nullptr;
-    DPXCHK(dpx_stream_create(ctx, in_fmt, out_fmt, args.samplerate, /*samplenr, main.rs:60*/ 0, slab_bytes, 3, &stream));   // kSlabs below
+    if (dpx_stream_create_multi(ctxs.data(), (int)ctxs.size(), in_fmt, out_fmt, args.samplerate, /*samplenr, main.rs:60*/ 0, slab_bytes,
+                                slabs_per_gpu, &stream) != DPX_OK) {
+        fprintf(stderr, "doppler: %s\n", dpx_last_error());
+        destroy_ctxs();
+        return 1;
+    }
 
-    // The ring is driven from two threads: this one reads stdin into slabs and submits them, the writer thread
-    // below waits for the oldest slab, writes it to stdout and frees it — read(), the GPU and write() overlap.
-    constexpr int kSlabs = 3;
+    // ---- shared state of the three sides (producer = this thread; consumer; recycling under `mu`)
     std::mutex mu;
     std::condition_variable cv;
-    uint64_t submitted = 0, drained = 0;    // guarded by mu
+    uint64_t acquired = 0, submitted = 0, handed = 0, released = 0;     // slab counts, guarded by mu
     bool input_done = false;
-    std::thread writer([&]() {
+    std::atomic<int> failure{0};            // exit status to use once everything has been wound down (0 = none)
+    std::string failure_msg;
+    auto fail_with = [&](int status, const std::string &msg) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (failure == 0) {
+            failure = status;
+            failure_msg = msg;
+        }
+        cv.notify_all();
+    };
+
+    struct SlabIo {             // per ring position
+        char *in = nullptr;
+        size_t filled = 0;      // bytes in the slab once `ready`
+        bool ready = false;     // fill finished (guarded by mu)
+        bool written = false;   // drain finished (guarded by mu)
+    };
+    std::vector<SlabIo> io((size_t)n_slabs);
+    std::unique_ptr<Workers> fillers, drainers;
+    if (in_file) fillers.reset(new Workers(io_threads));
+    if (out_file) drainers.reset(new Workers(io_threads));
+    const off_t out_base = out_file ? lseek(STDOUT_FILENO, 0, SEEK_CUR) : 0;
+
+    // ---- consumer: oldest slab -> stdout.  Pipe: write here, in order.  File: hand the slab to a drain worker with
+    // its offset; the recycling (dpx_stream_release, in order) happens as the oldest writes complete.
+    std::thread consumer([&]() {
+        off_t out_off = out_base < 0 ? 0 : out_base;
         for (;;) {
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return submitted > drained || input_done; });
-                if (submitted == drained) return;       // input_done and nothing left
+                cv.wait(lk, [&] { return submitted > handed || input_done || failure != 0; });
+                if (failure != 0 || submitted == handed) break;        // error, or input_done and nothing left
             }
             const void *out = nullptr;
             size_t nbytes = 0;
-            DPXCHK(dpx_stream_next(stream, &out, &nbytes));
-            if (!write_all(STDOUT_FILENO, static_cast<const char *>(out), nbytes)) {
-                info("doppler stdout.write error: %s", strerror(errno));       // main.rs:86
-                exit(1);
+            if (dpx_stream_next(stream, &out, &nbytes) != DPX_OK) {
+                fail_with(1, std::string("dpx_stream_next: ") + dpx_last_error());
+                break;
             }
-            DPXCHK(dpx_stream_release(stream));
+            uint64_t k;
             {
                 std::lock_guard<std::mutex> lk(mu);
-                ++drained;
+                k = handed++;
             }
-            cv.notify_all();
+            auto finish = [&, k](bool ok) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!ok && failure == 0) {
+                    failure = 101;                                       // main.rs:86-95: unwrap() on a failed write
+                    failure_msg = std::string("doppler stdout.write error: ") + strerror(errno);
+                }
+                io[k % io.size()].written = true;
+                while (released < handed && io[released % io.size()].written) {   // recycle in order
+                    io[released % io.size()].written = false;
+                    if (dpx_stream_release(stream) != DPX_OK && failure == 0) {
+                        failure = 1;
+                        failure_msg = std::string("dpx_stream_release: ") + dpx_last_error();
+                    }
+                    ++released;
+                }
+                cv.notify_all();
+            };
+            const char *p = static_cast<const char *>(out);
+            if (out_file) {
+                const off_t off = out_off;
+                drainers->push([=] { finish(write_all(STDOUT_FILENO, p, nbytes, true, off)); });
+            } else {
+                finish(write_all(STDOUT_FILENO, p, nbytes, false, 0));
+            }
+            out_off += (off_t)nbytes;
         }
+        if (drainers) drainers->stop();             // all queued writes are done when this returns
+        if (out_file && failure == 0 && out_off > 0) (void)lseek(STDOUT_FILENO, out_off, SEEK_SET);
     });
 
     // the reference's loop state
-    const bool replay = args.mode == dpx::Mode::Track && args.has_time;
     std::unique_ptr<dpx::ReplaySchedule> sched;
     if (args.mode == dpx::Mode::Track) {
         if (!range_rate) {
@@ -233,23 +413,25 @@ int main(int argc, char **argv)
     }
     int64_t last_log = 0;
     double last_wall_log = 0;
+    auto log_time = [](double unix_s) {            // "{:}" of Tm::rfc3339() in UTC: 2015-01-22T19:48:05Z
+        time_t t = (time_t)unix_s;
+        struct tm g;
+        gmtime_r(&t, &g);
+        char b[40];
+        strftime(b, sizeof(b), "%Y-%m-%dT%H:%M:%SZ", &g);
+        info("time                : %s", b);
+    };
+    const double live_start = live_track ? wall_clock() : 0;
 
-    bool eof = false, ragged = false;
+    bool ragged = false;
     uint64_t total_samples = 0;
     struct timeval tv_start;
     gettimeofday(&tv_start, nullptr);
     std::vector<dpx_segment> segs;
-    while (!eof) {
-        void *buf = nullptr;
-        size_t cap = 0;
-        {   // every slab in flight: wait for the writer to free the oldest
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return submitted - drained < (uint64_t)kSlabs; });
-        }
-        DPXCHK(dpx_stream_acquire(stream, &buf, &cap));
-        const size_t n = gather(STDIN_FILENO, static_cast<char *>(buf), cap, &eof);
+
+    // what happens to a slab once its bytes are in: schedule for its blocks, then submit (always in stream order)
+    auto submit_slab = [&](size_t n) -> bool {
         // main.rs:63-68: complete blocks always; the trailing short block only if it is whole samples
-        // (gather() stops only on block boundaries unless the input ended, so tail != 0 implies eof)
         const size_t full = n / DPX_BUFFER_SIZE * DPX_BUFFER_SIZE;
         size_t tail = n - full;
         if (tail % ibs != 0) {
@@ -259,8 +441,6 @@ int main(int argc, char **argv)
         const size_t use = full + tail;
         const size_t n_samples = use / ibs;
         total_samples += n_samples;
-
-        // shift schedule for the blocks of this slab
         segs.clear();
         const size_t spb = DPX_BUFFER_SIZE / ibs;
         const size_t n_blocks = (use + DPX_BUFFER_SIZE - 1) / DPX_BUFFER_SIZE;
@@ -268,18 +448,17 @@ int main(int argc, char **argv)
             if (n_samples) segs.push_back({(uint64_t)n_samples, (float)args.shift});   // main.rs:110
         } else {
             float wall_shift = 0;
-            if (!replay) {                 // main.rs:186-205: wall clock; one evaluation per slab
-                struct timeval tv;
-                gettimeofday(&tv, nullptr);
-                const double now = tv.tv_sec + tv.tv_usec * 1e-6;
+            if (live_track) {              // main.rs:186-205: wall clock, evaluated for this block (the slab IS one block)
+                const double now = wall_clock();
                 double rr;
                 dpx::LookAngles la;
                 if (sgp4) { la = sgp4->observe(observer, now); rr = la.range_rate_km_s; }
-                else rr = range_rate(0);
+                else rr = range_rate((int64_t)(now - live_start));          // table extension: whole seconds since start-up
                 const double doppler_hz = (rr * 1000.0 / 299792458.) * (double)args.frequency * (-1.0);
                 wall_shift = (float)doppler_hz + (float)(args.has_offset ? args.offset : 0);
-                if (now - last_wall_log >= 1.0) {
+                if (now - last_wall_log >= 1.0) {                              // main.rs:190-198: once per second of wall time
                     last_wall_log = now;
+                    log_time(now);
                     if (sgp4) {
                         info("az                  : %.2f\xC2\xB0", la.az_deg);
                         info("el                  : %.2f\xC2\xB0", la.el_deg);
@@ -296,7 +475,13 @@ int main(int argc, char **argv)
                     hz = sched->next_block_shift();
                     if (sched->dt_seconds() - last_log >= 5) {             // main.rs:167-175
                         last_log = sched->dt_seconds();
-                        info("time                : +%lld s", (long long)sched->dt_seconds());
+                        log_time((double)args.time_unix + (double)sched->dt_seconds());
+                        if (sgp4) {                                            // what predict.sat held: updated one block earlier
+                            const dpx::LookAngles la = sgp4->observe(observer, (double)args.time_unix + (double)sched->update_dt_seconds());
+                            info("az                  : %.2f\xC2\xB0", la.az_deg);
+                            info("el                  : %.2f\xC2\xB0", la.el_deg);
+                            info("range               : %.0f km", la.range_km);
+                        }
                         info("range rate          : %.3f km/sec", sched->last_range_rate());
                         info("doppler@%.3f MHz : %.2f Hz\n", (float)args.frequency / 1000000.0f, sched->last_doppler_hz());
                     }
@@ -306,29 +491,138 @@ int main(int argc, char **argv)
                 else segs.push_back({(uint64_t)cnt, hz});
             }
         }
-        DPXCHK(dpx_stream_submit(stream, use, segs.data(), segs.size()));
+        if (dpx_stream_submit(stream, use, segs.data(), segs.size()) != DPX_OK) {
+            fail_with(1, std::string("dpx_stream_submit: ") + dpx_last_error());
+            return false;
+        }
         {
             std::lock_guard<std::mutex> lk(mu);
             ++submitted;
         }
-        cv.notify_all();        // the writer hands every slab over as soon as it is done: on a live pipe the latency is one slab
+        cv.notify_all();        // the consumer hands every slab over as soon as it is done: on a live pipe the latency is one slab
+        return true;
+    };
+
+    if (!in_file) {
+        // ---- pipe / terminal: one reader, whatever is available
+        bool eof = false;
+        while (!eof && failure == 0) {
+            {   // every slab in use: wait for the oldest to be recycled
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return submitted - released < (uint64_t)n_slabs || failure != 0; });
+                if (failure != 0) break;
+            }
+            void *buf = nullptr;
+            size_t cap = 0;
+            if (dpx_stream_acquire(stream, &buf, &cap) != DPX_OK) {
+                fail_with(1, std::string("dpx_stream_acquire: ") + dpx_last_error());
+                break;
+            }
+            const ssize_t n = gather(STDIN_FILENO, static_cast<char *>(buf), cap, &eof);
+            if (n < 0) {
+                fail_with(101, "doppler collect error");                    // main.rs:63 expect()
+                (void)dpx_stream_submit(stream, 0, nullptr, 0);             // hand the acquired slab back empty
+                std::lock_guard<std::mutex> lk(mu);
+                ++submitted;
+                break;
+            }
+            if (!submit_slab((size_t)n)) break;
+        }
+    } else {
+        // ---- regular file: the loop of main.rs reads min(8192, remaining) per block until a short (or empty) read,
+        // i.e. it consumes the whole file; slab k holds bytes [k * slab_bytes, ...) and is filled by a worker.
+        const off_t start = lseek(STDIN_FILENO, 0, SEEK_CUR);
+        const uint64_t total = sin.st_size > (start < 0 ? 0 : start) ? (uint64_t)(sin.st_size - (start < 0 ? 0 : start)) : 0;
+        // the reference's last read is short or empty: when the size is a multiple of 8192 that is an extra, empty block
+        const uint64_t n_fill = total / slab_bytes + 1;                     // the last slab may be empty: it ends the stream
+        uint64_t next_fill = 0;
+        while (failure == 0) {
+            bool progressed = false;
+            // hand free slabs to the fill workers
+            for (;;) {
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (next_fill >= n_fill || acquired - released >= (uint64_t)n_slabs) break;
+                }
+                void *buf = nullptr;
+                size_t cap = 0;
+                if (dpx_stream_acquire(stream, &buf, &cap) != DPX_OK) {
+                    fail_with(1, std::string("dpx_stream_acquire: ") + dpx_last_error());
+                    break;
+                }
+                const uint64_t k = next_fill++;
+                const uint64_t off = k * (uint64_t)slab_bytes;
+                const size_t n = (size_t)std::min<uint64_t>(slab_bytes, total - std::min(total, off));
+                SlabIo &s = io[k % io.size()];
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    ++acquired;
+                    s.in = static_cast<char *>(buf);
+                    s.filled = n;
+                    s.ready = false;
+                }
+                char *dst = static_cast<char *>(buf);
+                const off_t foff = (off_t)((start < 0 ? 0 : start) + off);
+                fillers->push([&, dst, n, foff, k] {
+                    const bool ok = n == 0 || pread_all(STDIN_FILENO, dst, n, foff);
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (!ok && failure == 0) {
+                        failure = 101;                                  // main.rs:63 expect("doppler collect error")
+                        failure_msg = "doppler collect error";
+                    }
+                    io[k % io.size()].ready = true;
+                    cv.notify_all();
+                });
+                progressed = true;
+            }
+            // submit the filled slabs, in order
+            bool ready;
+            size_t n = 0;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ready = submitted < acquired && io[submitted % io.size()].ready;
+                if (ready) n = io[submitted % io.size()].filled;
+            }
+            if (ready) {
+                if (!submit_slab(n)) break;
+                progressed = true;
+                std::lock_guard<std::mutex> lk(mu);
+                if (submitted == n_fill) break;
+            }
+            if (!progressed) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] {
+                    return failure != 0 || (submitted < acquired && io[submitted % io.size()].ready) ||
+                           (next_fill < n_fill && acquired - released < (uint64_t)n_slabs);
+                });
+            }
+        }
+        if (fillers) fillers->stop();
+        (void)lseek(STDIN_FILENO, (off_t)((start < 0 ? 0 : start) + total), SEEK_SET);
     }
     {
         std::lock_guard<std::mutex> lk(mu);
         input_done = true;
     }
     cv.notify_all();
-    writer.join();
+    consumer.join();
 
     if (getenv("DOPPLER_STATS")) {      // steady-state rate: first read to last write, start-up excluded
         struct timeval tv_end;
         gettimeofday(&tv_end, nullptr);
         const double dt = (tv_end.tv_sec - tv_start.tv_sec) + (tv_end.tv_usec - tv_start.tv_usec) * 1e-6;
-        fprintf(stderr, "doppler stats: %llu samples in %.6f s = %.1f Msamples/s (stdin -> stdout, start-up excluded)\n",
-                (unsigned long long)total_samples, dt, total_samples / dt / 1e6);
+        fprintf(stderr, "doppler stats: %llu samples in %.6f s = %.1f Msamples/s (stdin -> stdout, start-up excluded; %u GPU(s), %d slabs of %zu bytes, %s in, %s out)\n",
+                (unsigned long long)total_samples, dt, total_samples / dt / 1e6, n_gpus, n_slabs, slab_bytes,
+                in_file ? "pread workers" : "one reader", out_file ? "pwrite workers" : "one writer");
     }
+    (void)obs;
     dpx_stream_destroy(stream);
-    dpx_ctx_destroy(ctx);
+    destroy_ctxs();
+    if (failure != 0) {
+        if (failure == 101) fprintf(stderr, "thread 'main' panicked at '%s'\n", failure_msg.c_str());
+        else fprintf(stderr, "doppler: %s\n", failure_msg.c_str());
+        return failure;
+    }
     if (ragged) {
         fprintf(stderr, "thread 'main' panicked at 'assertion failed: inbuf.len() %% %zu == 0'\n", ibs);
         return 101;

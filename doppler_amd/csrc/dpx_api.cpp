@@ -53,6 +53,7 @@ struct dpx_ctx {
     int variant = 0;
     int choice = dpx::kChooseAuto;   // which kernels finalize() may use (dpx_set_tuning)
     dpx::PlanTuning tuning;          // kernel-shape knobs (dpx_set_options)
+    dpx::PeriodCache periods;        // period per ratio seen so far (one producer thread plans at a time)
     hipStream_t stream = nullptr;   // internal stream of the host-pointer entry points
     void *stage_in = nullptr;
     void *stage_out = nullptr;
@@ -137,6 +138,23 @@ dpx::PlanTuning tuning_of(const dpx_options *o)
     t.walk_table_rows = o->walk_table_rows;
     t.walk_tilemin = o->walk_tilemin;
     return t;
+}
+
+// the stretch list of a segment list (counter carried from segment to segment), periods scanned in parallel first
+void append_segments(dpx::PlanResult &plan, const dpx_segment *segs, size_t n_segs, uint32_t samplerate, uint32_t &sn,
+                     int variant, dpx::PeriodCache &cache)
+{
+    if (n_segs >= 16) {
+        std::vector<float> ratios(n_segs);
+        std::vector<uint64_t> counts(n_segs);
+        for (size_t i = 0; i < n_segs; ++i) {
+            ratios[i] = dpx::ratio_of(segs[i].shift_hz, samplerate);
+            counts[i] = segs[i].n_samples;
+        }
+        cache.prefetch(ratios.data(), counts.data(), n_segs);
+    }
+    for (size_t i = 0; i < n_segs; ++i)
+        dpx::plan_append(plan, dpx::ratio_of(segs[i].shift_hz, samplerate), segs[i].n_samples, sn, variant, &cache);
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -244,7 +262,7 @@ int run_host_small(dpx_ctx *ctx, const void *in, size_t n, int in_fmt, void *out
     }
     dpx::PlanResult plan;
     uint32_t sn = *samplenum;
-    dpx::plan_append(plan, dpx::ratio_of(shift_hz, samplerate), n, sn, 1 /* sincos per sample */);
+    dpx::plan_append(plan, dpx::ratio_of(shift_hz, samplerate), n, sn, 1 /* sincos per sample */, &ctx->periods);
     const dpx::LaunchGeom g = geometry(ctx);
     dpx::finalize(plan, g.tile(), dpx::kChooseTileOnly);
     if (plan.error) return fail(DPX_ERR_PLAN, "%s", plan.error);
@@ -279,7 +297,7 @@ int run_host(dpx_ctx *ctx, const void *in, size_t n, int in_fmt, void *out, int 
     }
     dpx::PlanResult plan;
     uint32_t sn = *samplenum;
-    dpx::plan_append(plan, dpx::ratio_of(shift_hz, samplerate), n, sn, ctx->variant);
+    dpx::plan_append(plan, dpx::ratio_of(shift_hz, samplerate), n, sn, ctx->variant, &ctx->periods);
     if (n == 0) {
         *samplenum = sn;
         return DPX_OK;
@@ -539,8 +557,8 @@ int dpx_plan_describe(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
     static_assert(sizeof(dpx_stretch) == sizeof(dpx::StretchView), "dpx_stretch mirrors the head of DevSeg");
     dpx::PlanResult plan;
     uint32_t sn = samplenum0;
-    for (size_t i = 0; i < n_segs; ++i)
-        dpx::plan_append(plan, dpx::ratio_of(segs[i].shift_hz, samplerate), segs[i].n_samples, sn, variant);
+    dpx::PeriodCache cache;
+    append_segments(plan, segs, n_segs, samplerate, sn, variant, cache);
     *n_out = plan.segs.size();
     for (size_t i = 0; i < plan.segs.size() && i < cap; ++i) memcpy(&out[i], &plan.segs[i], sizeof(dpx_stretch));
     if (final_samplenum) *final_samplenum = sn;
@@ -555,8 +573,8 @@ int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
     dpx::PlanResult plan;
     uint32_t sn = samplenum0;
     const int v = variant >= 3 ? 0 : variant;
-    for (size_t i = 0; i < n_segs; ++i)
-        dpx::plan_append(plan, dpx::ratio_of(segs[i].shift_hz, samplerate), segs[i].n_samples, sn, v);
+    dpx::PeriodCache cache;
+    append_segments(plan, segs, n_segs, samplerate, sn, v, cache);
     if (plan.n_samples != n_samples) return fail(DPX_ERR_PLAN, "segments hold %llu samples, buffers %llu",
                                                  (unsigned long long)plan.n_samples, (unsigned long long)n_samples);
     dpx::LaunchGeom g;
@@ -575,8 +593,8 @@ int dpx_plan_layout(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
     dpx::PlanResult plan;
     uint32_t sn = samplenum0;
     const int v = variant >= 3 ? 0 : variant;
-    for (size_t i = 0; i < n_segs; ++i)
-        dpx::plan_append(plan, dpx::ratio_of(segs[i].shift_hz, samplerate), segs[i].n_samples, sn, v);
+    dpx::PeriodCache cache;
+    append_segments(plan, segs, n_segs, samplerate, sn, v, cache);
     dpx::LaunchGeom g;
     g.block = block ? block : 128;
     g.vecs = vecs ? vecs : 2;
@@ -689,9 +707,7 @@ int dpx_plan_segments(dpx_ctx *ctx, const dpx_segment *segs, size_t n_segs, uint
     p->fma = ctx->fma;
     uint32_t sn = samplenum0;
     p->host.final_samplenum = sn;
-    for (size_t i = 0; i < n_segs; ++i)
-        dpx::plan_append(p->host, dpx::ratio_of(segs[i].shift_hz, samplerate), segs[i].n_samples, sn,
-                         ctx->variant);
+    append_segments(p->host, segs, n_segs, samplerate, sn, ctx->variant, ctx->periods);
     dpx::finalize(p->host, p->geom.tile(), ctx->choice, ctx->tuning);
     hipError_t e = hipSetDevice(ctx->device);
     int rc = e == hipSuccess ? DPX_OK : fail(DPX_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
@@ -757,6 +773,7 @@ int dpx_run_device(dpx_plan *plan, const void *d_in, int in_fmt, void *d_out, in
 /* ------------------------------------------------------------------ streaming */
 
 struct dpx_stream_slab {
+    dpx_ctx *ctx = nullptr;      // the GPU this slab is processed on (slab k of the ring belongs to context k mod n)
     char *h_in = nullptr, *h_out = nullptr;
     void *d_in = nullptr, *d_out = nullptr;
     hipStream_t stream = nullptr;
@@ -770,39 +787,49 @@ struct dpx_stream_slab {
 };
 
 struct dpx_stream {
-    dpx_ctx *ctx = nullptr;
+    dpx_ctx *ctx = nullptr;      // first context: holds the period cache and the tuning all slabs are planned with
+    std::vector<dpx_ctx *> ctxs;
     int in_fmt = 0, out_fmt = 0;
     uint32_t samplerate = 0, samplenum = 0;
     size_t slab_bytes = 0, slab_out = 0;
     std::vector<dpx_stream_slab> slabs;
-    size_t head = 0;    // next slab to acquire            (producer side: acquire / submit)
-    size_t tail = 0;    // oldest submitted slab           (consumer side: next / release)
+    size_t acq = 0;     // next slab to acquire            (producer side: acquire, then submit in the same order)
+    size_t head = 0;    // oldest acquired slab, the next to submit
+    size_t tail = 0;    // oldest submitted slab not yet handed out   (consumer side: next)
+    size_t rel = 0;     // oldest handed-out slab                     (release, in the same order)
     std::atomic<int> in_flight{0};
 };
 
-int dpx_stream_create(dpx_ctx *ctx, int in_fmt, int out_fmt, uint32_t samplerate, uint32_t samplenum0,
-                      size_t slab_bytes, int n_slabs, dpx_stream **out)
+int dpx_stream_create_multi(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_fmt, uint32_t samplerate,
+                            uint32_t samplenum0, size_t slab_bytes, int slabs_per_ctx, dpx_stream **out)
 {
-    if (!ctx || !out || !fmt_ok(in_fmt) || !fmt_ok(out_fmt) || n_slabs < 1 || n_slabs > 64)
+    if (!ctxs || n_ctx < 1 || n_ctx > 64 || !out || !fmt_ok(in_fmt) || !fmt_ok(out_fmt) || slabs_per_ctx < 1 ||
+        (long)slabs_per_ctx * n_ctx > 256)
         return fail(DPX_ERR_ARG, "bad argument");
+    for (int i = 0; i < n_ctx; ++i)
+        if (!ctxs[i]) return fail(DPX_ERR_ARG, "context %d is null", i);
     *out = nullptr;
     const size_t ibs = bytes_per_sample(in_fmt), obs = bytes_per_sample(out_fmt);
     slab_bytes = slab_bytes / 16 * 16;
     if (slab_bytes < 16) return fail(DPX_ERR_ARG, "slab_bytes must be at least 16");
-    DPX_HIP(hipSetDevice(ctx->device));
     dpx_stream *s = new (std::nothrow) dpx_stream;
     if (!s) return fail(DPX_ERR_ARG, "out of host memory");
-    s->ctx = ctx;
+    s->ctx = ctxs[0];
+    s->ctxs.assign(ctxs, ctxs + n_ctx);
     s->in_fmt = in_fmt;
     s->out_fmt = out_fmt;
     s->samplerate = samplerate;
     s->samplenum = samplenum0;
     s->slab_bytes = slab_bytes;
     s->slab_out = slab_bytes / ibs * obs;
-    s->slabs.resize((size_t)n_slabs);
-    for (dpx_stream_slab &b : s->slabs) {
-        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&b.h_in), slab_bytes, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_out), s->slab_out + 16, hipHostMallocDefault);
+    s->slabs.resize((size_t)slabs_per_ctx * (size_t)n_ctx);
+    for (size_t k = 0; k < s->slabs.size(); ++k) {
+        dpx_stream_slab &b = s->slabs[k];
+        b.ctx = ctxs[k % (size_t)n_ctx];                 // consecutive slabs on consecutive GPUs: their copies and kernels overlap
+        hipError_t e = hipSetDevice(b.ctx->device);
+        // portable: pinned for every device of the process, so that any slab can be handed to any GPU's DMA engines
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_in), slab_bytes, hipHostMallocPortable);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_out), s->slab_out + 16, hipHostMallocPortable);
         if (e == hipSuccess) e = hipMalloc(&b.d_in, slab_bytes);
         if (e == hipSuccess) e = hipMalloc(&b.d_out, s->slab_out + 16);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking);
@@ -816,11 +843,18 @@ int dpx_stream_create(dpx_ctx *ctx, int in_fmt, int out_fmt, uint32_t samplerate
     return DPX_OK;
 }
 
+int dpx_stream_create(dpx_ctx *ctx, int in_fmt, int out_fmt, uint32_t samplerate, uint32_t samplenum0,
+                      size_t slab_bytes, int n_slabs, dpx_stream **out)
+{
+    if (!ctx) return fail(DPX_ERR_ARG, "bad argument");
+    return dpx_stream_create_multi(&ctx, 1, in_fmt, out_fmt, samplerate, samplenum0, slab_bytes, n_slabs, out);
+}
+
 void dpx_stream_destroy(dpx_stream *s)
 {
     if (!s) return;
-    (void)hipSetDevice(s->ctx->device);
     for (dpx_stream_slab &b : s->slabs) {
+        if (b.ctx) (void)hipSetDevice(b.ctx->device);
         if (b.stream) (void)hipStreamSynchronize(b.stream);
         if (b.h_in) (void)hipHostFree(b.h_in);
         if (b.h_out) (void)hipHostFree(b.h_out);
@@ -836,14 +870,10 @@ void dpx_stream_destroy(dpx_stream *s)
 int dpx_stream_acquire(dpx_stream *s, void **pinned_in, size_t *capacity_bytes)
 {
     if (!s || !pinned_in) return fail(DPX_ERR_ARG, "bad argument");
-    dpx_stream_slab &b = s->slabs[s->head];
-    if (b.state == 1) {             // acquire twice without submit: same buffer again
-        *pinned_in = b.h_in;
-        if (capacity_bytes) *capacity_bytes = s->slab_bytes;
-        return DPX_OK;
-    }
-    if (b.state != 0) return fail(DPX_ERR_PLAN, "all %zu slabs are in flight: call dpx_stream_next/release first", s->slabs.size());
+    dpx_stream_slab &b = s->slabs[s->acq];
+    if (b.state != 0) return fail(DPX_ERR_PLAN, "all %zu slabs are in use: call dpx_stream_next/release first", s->slabs.size());
     b.state = 1;
+    s->acq = (s->acq + 1) % s->slabs.size();
     *pinned_in = b.h_in;
     if (capacity_bytes) *capacity_bytes = s->slab_bytes;
     return DPX_OK;
@@ -862,18 +892,18 @@ int dpx_stream_submit(dpx_stream *s, size_t in_bytes, const dpx_segment *segs, s
     for (size_t i = 0; i < n_segs; ++i) total += segs[i].n_samples;
     if (total != in_bytes / ibs) return fail(DPX_ERR_PLAN, "segments hold %llu samples, the slab %zu",
                                              (unsigned long long)total, in_bytes / ibs);
-    dpx_ctx *ctx = s->ctx;
-    DPX_HIP(hipSetDevice(ctx->device));
+    dpx_ctx *ctx = s->ctx;                 // planning state (period cache, tuning): the first context's
+    DPX_HIP(hipSetDevice(b.ctx->device));  // the device work: this slab's GPU
     b.plan = dpx::PlanResult();
     uint32_t sn = s->samplenum;
-    for (size_t i = 0; i < n_segs; ++i)
-        dpx::plan_append(b.plan, dpx::ratio_of(segs[i].shift_hz, s->samplerate), segs[i].n_samples, sn, ctx->variant);
+    // the context remembers every ratio's period: a constant shift is scanned once per run, not once per slab
+    append_segments(b.plan, segs, n_segs, s->samplerate, sn, ctx->variant, ctx->periods);
     const dpx::LaunchGeom g = geometry(ctx);
     dpx::finalize(b.plan, g.tile(), ctx->choice, ctx->tuning);
     if (b.plan.error) return fail(DPX_ERR_PLAN, "%s", b.plan.error);
     b.out_bytes = (size_t)total * obs;
     if (total) {
-        int rc = materialize(ctx, b.plan, b.dev, ctx->fma, b.stream);
+        int rc = materialize(b.ctx, b.plan, b.dev, ctx->fma, b.stream);
         if (rc != DPX_OK) return rc;
         DPX_HIP(hipMemcpyAsync(b.d_in, b.h_in, in_bytes, hipMemcpyHostToDevice, b.stream));
         rc = run_plan(b.plan, b.dev, b.d_in, s->in_fmt, b.d_out, s->out_fmt, ctx->fma, g, b.stream);
@@ -899,10 +929,10 @@ int dpx_stream_next(dpx_stream *s, const void **pinned_out, size_t *out_bytes)
 {
     if (!s || !pinned_out || !out_bytes) return fail(DPX_ERR_ARG, "bad argument");
     dpx_stream_slab &b = s->slabs[s->tail];
-    if (b.state == 3) return fail(DPX_ERR_PLAN, "dpx_stream_next twice without dpx_stream_release");
     if (b.state != 2) return fail(DPX_ERR_PLAN, "nothing in flight");
     DPX_HIP(hipEventSynchronize(b.done));
     b.state = 3;
+    s->tail = (s->tail + 1) % s->slabs.size();
     *pinned_out = b.h_out;
     *out_bytes = b.out_bytes;
     return DPX_OK;
@@ -911,10 +941,10 @@ int dpx_stream_next(dpx_stream *s, const void **pinned_out, size_t *out_bytes)
 int dpx_stream_release(dpx_stream *s)
 {
     if (!s) return fail(DPX_ERR_ARG, "bad argument");
-    dpx_stream_slab &b = s->slabs[s->tail];
+    dpx_stream_slab &b = s->slabs[s->rel];
     if (b.state != 3) return fail(DPX_ERR_PLAN, "dpx_stream_release without dpx_stream_next");
     b.state = 0;
-    s->tail = (s->tail + 1) % s->slabs.size();
+    s->rel = (s->rel + 1) % s->slabs.size();
     s->in_flight--;
     return DPX_OK;
 }

@@ -449,12 +449,10 @@ __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_
     // the wavefronts of the workgroup that have not terminated (CDNA ISA, S_BARRIER: a wave that has ended is no
     // longer waited for), so the survivors' barrier completes; tests/test_gpu_parity.py runs every workgroup shape
     // with row counts that leave 1..WAVES-1 wavefronts without rows.
-    // In table mode the first kWalkSlice / 2 threads have requested the slice (16 bytes each) and must deliver it; when
-    // the workgroup evaluates the slice itself, the wavefronts WITH rows share that work among themselves — a
-    // wavefront without rows then holds no slot while the others wait for their samples, which is what keeps short
-    // chunks (matrices of few rows) from starving the CU of loads in flight.
-    const uint32_t n_act = (ws.row_end - ws.row0 + U - 1) / U;          // wavefronts with rows: 1..WAVES (uniform)
-    if (r0 >= ws.row_end && (compute || wave * kRowsLanes >= kWalkSlice / 2)) return;
+    // Measured alternative (profiles/r02_walk.md): only the wavefronts WITH rows evaluate the slice, so that the others
+    // leave at once — slower everywhere (the serial evaluations delay the surviving wavefronts past their loads).
+    const uint32_t slice_threads = compute ? kWalkSlice : kWalkSlice / 2;
+    if (r0 >= ws.row_end && wave * kRowsLanes >= slice_threads) return;
     qvec qin[U][NV];
     uint32_t off[U];                                          // slice entry of the row's column 0 (uniform per wavefront)
     uint8_t *op[U][NV];
@@ -482,12 +480,12 @@ __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_
     }
 
     if (compute) {                                            // uniform for the workgroup
-        // the threads of the wavefronts with rows evaluate entries tid, tid + 64 n_act, ... with the bit-exact sincos —
-        // after the sample loads above have been issued, so the evaluation runs in the shadow of the HBM latency
+        // thread j evaluates entry j (threads 0..31 also entry 256 + j) with the bit-exact sincos — after the sample
+        // loads above have been issued, so the evaluation runs in the shadow of the HBM latency
         const uint32_t P = ws.period;
         // counter of column c: ((phase + c) mod P) + 1, c = 256 w + j - kWalkPad >= -kWalkPad
         const uint32_t ub = ws.phase + w * kWalkWindow;       // < period + L + 255 < 2^24
-        for (uint32_t j = tid; j < kWalkSlice; j += n_act * kRowsLanes) {
+        for (uint32_t j = tid; j < kWalkSlice; j += THREADS) {
             uint32_t t;
             if (ws.L == P) {                                  // P >= kWalkMinL > kWalkPad: at most two wraps
                 t = ub + j + P - kWalkPad;

@@ -3,12 +3,15 @@
 // reference's (src/dsp.rs:121,125).
 #include "dpx_planner.h"
 
+#include <immintrin.h>
 #include <math.h>
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
+#include <thread>
+#include <utility>
 
 namespace dpx {
 
@@ -33,12 +36,45 @@ bool is_reset(float ratio, uint32_t n)
     return product_is_integer(p);
 }
 
+// The scan is the planner's whole cost (a period is 10^4..10^6 candidates), so where the host has AVX2 it runs eight
+// candidates per instruction in blocks, and only a block that holds a reset is looked at candidate by candidate.  Every
+// candidate still gets exactly the reference's arithmetic: fl32(ratio * fl32(n)) — one IEEE multiply per lane, the
+// int -> f32 conversion in the current (nearest-even) rounding mode — and the same test as product_is_integer().
+__attribute__((target("avx2")))
+static int block_has_reset_avx2(float ratio, uint32_t n0, int len)      // candidates n0 .. n0 + len - 1 < 2^31, len % 8 == 0
+{
+    const __m256 r = _mm256_set1_ps(ratio);
+    const __m256 two23 = _mm256_set1_ps(8388608.0f), fmax = _mm256_set1_ps(3.4028234663852886e38f);
+    const __m256 absmask = _mm256_castsi256_ps(_mm256_set1_epi32(0x7fffffff));
+    __m256i n = _mm256_add_epi32(_mm256_set1_epi32((int)n0), _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7));
+    const __m256i step = _mm256_set1_epi32(8);
+    __m256 acc = _mm256_setzero_ps();
+    for (int i = 0; i < len; i += 8) {
+        const __m256 p = _mm256_mul_ps(r, _mm256_cvtepi32_ps(n));
+        const __m256 ap = _mm256_and_ps(p, absmask);
+        const __m256 t = _mm256_cvtepi32_ps(_mm256_cvttps_epi32(p));       // only looked at where |p| < 2^23
+        const __m256 small = _mm256_cmp_ps(ap, two23, _CMP_LT_OQ);
+        const __m256 same = _mm256_cmp_ps(t, p, _CMP_EQ_OQ);
+        const __m256 finite = _mm256_cmp_ps(ap, fmax, _CMP_LE_OQ);         // false for inf and nan
+        acc = _mm256_or_ps(acc, _mm256_or_ps(_mm256_and_ps(small, same), _mm256_andnot_ps(small, finite)));
+        n = _mm256_add_epi32(n, step);
+    }
+    return _mm256_movemask_ps(acc) != 0;
+}
+
+static const bool kHaveAvx2 = __builtin_cpu_supports("avx2");
+
 bool find_reset(float ratio, uint32_t n_start, uint64_t max_scan, uint32_t *n_reset)
 {
     const uint64_t to_wrap = (1ULL << 32) - (uint64_t)n_start;
     const uint64_t span = std::min(max_scan, to_wrap);
     uint64_t n = n_start;
     const uint64_t end = (uint64_t)n_start + span;
+    constexpr int kBlock = 256;
+    while (kHaveAvx2 && n + kBlock <= end && n + kBlock <= (1ULL << 31)) {
+        if (block_has_reset_avx2(ratio, (uint32_t)n, kBlock)) break;   // the first reset is in this block: find it below
+        n += kBlock;
+    }
     for (; n < end; ++n) {
         const float p = ratio * (float)(uint32_t)n;
         if (product_is_integer(p)) {
@@ -47,6 +83,50 @@ bool find_reset(float ratio, uint32_t n_start, uint64_t max_scan, uint32_t *n_re
         }
     }
     return false;
+}
+
+// first reset from counter 1 on, remembered per ratio (bit pattern): the period of every steady stretch with that ratio.
+// Only candidates below `limit` are ever scanned (a caller never needs to know about resets beyond its own samples);
+// what has been scanned without finding one is remembered too.  Returns 0 if there is no reset in [1, limit).
+uint32_t PeriodCache::period(float ratio, uint64_t limit)
+{
+    uint32_t bits;
+    memcpy(&bits, &ratio, sizeof bits);
+    Entry &e = first_reset[bits];               // {0, 1} when new: nothing found, scanned up to (excluding) 1
+    if (e.period != 0) return e.period < limit ? e.period : 0;
+    limit = std::min<uint64_t>(limit, 1ULL << 32);
+    if (e.scanned_to >= limit) return 0;
+    uint32_t p1 = 0;
+    if (find_reset(ratio, (uint32_t)e.scanned_to, limit - e.scanned_to, &p1)) {
+        e.period = p1;
+        return p1;
+    }
+    e.scanned_to = limit;
+    return 0;
+}
+
+// Periods of many ratios at once: the scans are independent of each other (only the lead-ins of plan_append depend on
+// the carried counter), so a long segment list — a track replay has one ratio per second of stream — is scanned on
+// several host threads before the sequential pass, which then finds every period in the cache.
+void PeriodCache::prefetch(const float *ratios, const uint64_t *counts, size_t n)
+{
+    std::vector<std::pair<float, uint64_t>> todo;
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t bits;
+        memcpy(&bits, &ratios[i], sizeof bits);
+        if (first_reset.find(bits) != first_reset.end()) continue;
+        first_reset[bits];                                   // entries exist before the threads start: no insertions later
+        todo.push_back({ratios[i], counts[i] + 1});
+    }
+    const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t n_threads = std::min<size_t>({hw, 16, todo.size() / 8});
+    if (n_threads < 2) return;                               // plan_append scans on demand
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < n_threads; ++t)
+        pool.emplace_back([&, t] {
+            for (size_t i = t; i < todo.size(); i += n_threads) period(todo[i].first, todo[i].second);   // distinct entries
+        });
+    for (std::thread &th : pool) th.join();
 }
 
 static uint32_t lut_len_for(uint32_t period, uint64_t count, int variant)
@@ -75,16 +155,30 @@ static void emit(PlanResult &plan, uint64_t first, uint64_t count, float ratio, 
     plan.segs.push_back(s);
 }
 
-void plan_append(PlanResult &plan, float ratio, uint64_t count, uint32_t &samplenum, int variant)
+void plan_append(PlanResult &plan, float ratio, uint64_t count, uint32_t &samplenum, int variant, PeriodCache *cache)
 {
+    PeriodCache local;
+    if (!cache) cache = &local;
     uint64_t pos = plan.n_samples;
     uint64_t remaining = count;
     uint32_t n = samplenum;
     while (remaining > 0) {
+        // P = first reset from 1 (one scan per ratio).  From a counter in [1, P] the next reset is P itself and the
+        // counter then cycles 1..P: no scan at all.  Otherwise (counter 0, or carried over from another ratio beyond
+        // P) the counter runs linearly to its next reset, which is found by scanning from it.
+        const uint32_t P = n >= 1 ? cache->period(ratio, (uint64_t)n + remaining) : 0;
+        if (P != 0 && n <= P) {
+            emit(plan, pos, remaining, ratio, n, P, lut_len_for(P, remaining, variant));
+            n = (uint32_t)(((uint64_t)(n - 1u) + remaining) % P) + 1u;
+            pos += remaining;
+            remaining = 0;
+            break;
+        }
         const uint64_t to_wrap = (1ULL << 32) - (uint64_t)n;
         const uint64_t span = std::min(remaining, to_wrap);
         uint32_t n1 = 0;
-        if (!find_reset(ratio, n, span, &n1)) {
+        const bool none_ahead = P == 0 && n >= 1;        // no reset in [1, n + remaining): none among this call's counters
+        if (none_ahead || !find_reset(ratio, n, span, &n1)) {
             // no reset among the next `span` counter values: n = n_start + j
             emit(plan, pos, span, ratio, n, 0, 0);
             pos += span;
@@ -92,24 +186,12 @@ void plan_append(PlanResult &plan, float ratio, uint64_t count, uint32_t &sample
             n = (uint32_t)((uint64_t)n + span);     // u32 `+= 1` wraps to 0 after 2^32-1
             continue;
         }
-        // the sample that uses n1 resets the counter to 1
-        uint32_t p1 = 0;
-        const bool steady = n >= 1 && find_reset(ratio, 1, n1, &p1) && p1 == n1;
-        if (steady) {
-            // no reset in [1, n1): the counter cycles 1..P with P = n1 from here on
-            const uint32_t P = n1;
-            emit(plan, pos, remaining, ratio, n, P, lut_len_for(P, remaining, variant));
-            n = (uint32_t)(((uint64_t)(n - 1u) + remaining) % P) + 1u;
-            pos += remaining;
-            remaining = 0;
-        } else {
-            // lead-in (n == 0, or a counter carried over from another ratio): linear up to n1
-            const uint64_t len = (uint64_t)n1 - n + 1;
-            emit(plan, pos, len, ratio, n, 0, 0);
-            pos += len;
-            remaining -= len;
-            n = 1;
-        }
+        // lead-in: linear up to n1; the sample that uses n1 resets the counter to 1
+        const uint64_t len = (uint64_t)n1 - n + 1;
+        emit(plan, pos, len, ratio, n, 0, 0);
+        pos += len;
+        remaining -= len;
+        n = 1;
     }
     plan.n_samples = pos;
     samplenum = n;

@@ -7,8 +7,10 @@
 // f32/integer host work, exact) and describes the stream as a short list of
 // DevSeg stretches in which n is a closed form of the sample index.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
+#include <unordered_map>
 #include <vector>
 
 #include "dpx_types.h"
@@ -77,8 +79,16 @@ struct PlanResult {
     const char *error = nullptr;     // set by finalize() when the plan cannot be laid out
 };
 
+// period (first reset from counter 1) per ratio bit pattern; a context or stream keeps one so that a ratio is scanned once
+struct PeriodCache {
+    struct Entry { uint32_t period = 0; uint64_t scanned_to = 1; };
+    std::unordered_map<uint32_t, Entry> first_reset;
+    uint32_t period(float ratio, uint64_t limit);     // first reset in [1, limit), or 0
+    void prefetch(const float *ratios, const uint64_t *counts, size_t n);   // scan many ratios on several threads
+};
+
 // variant: 0 auto, 1 sincos per sample wherever the period allows (>= 4), 2 tables whenever they fit
-void plan_append(PlanResult &plan, float ratio, uint64_t count, uint32_t &samplenum, int variant);
+void plan_append(PlanResult &plan, float ratio, uint64_t count, uint32_t &samplenum, int variant, PeriodCache *cache = nullptr);
 
 // after the last plan_append: choose the kernel for every stretch, lay out the
 // corrector tables, build the hint table and the launch list.

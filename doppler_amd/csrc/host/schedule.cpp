@@ -6,6 +6,7 @@ namespace dpx {
 float ReplaySchedule::next_block_shift()
 {
     const double SPEED_OF_LIGHT_M_S = 299792458.;        // main.rs:48
+    update_dt_ = dt_;
     last_rr_ = rr_(dt_);
     doppler_hz_ = (last_rr_ * 1000.0 / SPEED_OF_LIGHT_M_S) * (double)frequency_ * (-1.0);
     volatile float q = (float)sample_count_ / (float)samplerate_;

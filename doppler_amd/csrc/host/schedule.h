@@ -29,6 +29,7 @@ public:
     void block_done(size_t count) { sample_count_ += count; }
 
     int64_t dt_seconds() const { return dt_; }
+    int64_t update_dt_seconds() const { return update_dt_; }   // the dt the last predict.update() was given (one block behind)
     double last_doppler_hz() const { return doppler_hz_; }
     double last_range_rate() const { return last_rr_; }
 
@@ -37,7 +38,7 @@ private:
     uint32_t samplerate_, frequency_;
     int32_t offset_;
     uint64_t sample_count_ = 0;
-    int64_t dt_ = 0;
+    int64_t dt_ = 0, update_dt_ = 0;
     double doppler_hz_ = 0, last_rr_ = 0;
 };
 

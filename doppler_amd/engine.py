@@ -163,12 +163,16 @@ class Stream:
     the outputs in order.  The sample counter is carried from slab to slab like `samplenr` (main.rs:60)."""
 
     def __init__(self, ctx, in_fmt, out_fmt, samplerate, samplenum=0, slab_bytes=8 << 20, n_slabs=3):
+        """ctx: one Context, or a list of Contexts (one per GPU; slab k runs on context k mod len(ctx), n_slabs slabs
+        per context)."""
         self._lib = _lib_handle()
-        self.ctx = ctx
+        self.ctxs = list(ctx) if isinstance(ctx, (list, tuple)) else [ctx]
+        self.ctx = self.ctxs[0]
         self.in_fmt, self.out_fmt = fmt_code(in_fmt), fmt_code(out_fmt)
         self._h = C.c_void_p()
-        check(self._lib.dpx_stream_create(ctx.handle, self.in_fmt, self.out_fmt, int(samplerate), int(samplenum),
-                                          int(slab_bytes), int(n_slabs), C.byref(self._h)))
+        arr = (C.c_void_p * len(self.ctxs))(*[c.handle.value for c in self.ctxs])
+        check(self._lib.dpx_stream_create_multi(arr, len(self.ctxs), self.in_fmt, self.out_fmt, int(samplerate),
+                                                int(samplenum), int(slab_bytes), int(n_slabs), C.byref(self._h)))
 
     def acquire(self):
         """numpy uint8 view of the next free pinned input slab (raises DspError ERR_PLAN when all are in flight)."""

@@ -220,18 +220,28 @@ int dpx_run_device(dpx_plan *plan, const void *d_in, int in_fmt, void *d_out, in
  * draining overlap.  Zero-copy on the host side: the caller reads into / writes out of the pinned
  * buffers.  The sample counter (`samplenr`, main.rs:60) is carried from slab to slab.
  *
- *   dpx_stream_acquire  -> pinned input buffer of the next free slab (slab_bytes capacity); when
- *                          every slab is in flight it returns DPX_ERR_PLAN: drain one first
- *   dpx_stream_submit   -> that slab now holds in_bytes of IQ with the given constant-shift
+ *   dpx_stream_acquire  -> pinned input buffer of the next free slab (slab_bytes capacity); several slabs may be
+ *                          acquired before the first is submitted (they can then be filled in parallel); when every
+ *                          slab is in use it returns DPX_ERR_PLAN: drain one first
+ *   dpx_stream_submit   -> the OLDEST acquired slab now holds in_bytes of IQ with the given constant-shift
  *                          segments (their sample counts must add up to in_bytes); asynchronous
- *   dpx_stream_next     -> oldest submitted slab: waits for it, returns its pinned output
- *   dpx_stream_release  -> that output has been consumed; the slab is free again
+ *   dpx_stream_next     -> oldest submitted slab not yet handed out: waits for it, returns its pinned output; several
+ *                          outputs may be handed out before the first is released (they can be drained in parallel)
+ *   dpx_stream_release  -> the OLDEST handed-out output has been consumed; its slab is free again
  * Outputs come back in submission order.
- * Threads: one producer thread (acquire / submit) and one consumer thread (next / release) may drive the same
- * stream concurrently, as the `doppler` command does; any other sharing needs the caller's own lock. */
+ * Threads: acquire + submit form the producer side, next the consumer side, release the recycling side; each side may
+ * live on its own thread (one caller at a time per side), as in the `doppler` command. */
 typedef struct dpx_stream dpx_stream;
 int dpx_stream_create(dpx_ctx *ctx, int in_fmt, int out_fmt, uint32_t samplerate, uint32_t samplenum0,
                       size_t slab_bytes, int n_slabs, dpx_stream **stream);
+/* The same ring over several GPUs of one node (the product form of the time-chunk sharding: slabs ARE time chunks).
+ * ctxs: one context per GPU (a device may be listed more than once: separate contexts on it); slab k of the ring is
+ * processed on context k mod n_ctx, so consecutive slabs run on consecutive GPUs and their PCIe copies and kernels
+ * overlap.  The counter is carried on the host from slab to slab (closed form per slab: no GPU waits for another),
+ * every GPU writes its output straight into its own pinned host slab (per-GPU D2H, no gather through one GPU), and
+ * dpx_stream_next still hands the outputs back in submission order.  Tuning and libm choice are taken from ctxs[0]. */
+int dpx_stream_create_multi(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_fmt, uint32_t samplerate,
+                            uint32_t samplenum0, size_t slab_bytes, int slabs_per_ctx, dpx_stream **stream);
 int dpx_stream_acquire(dpx_stream *s, void **pinned_in, size_t *capacity_bytes);
 int dpx_stream_submit(dpx_stream *s, size_t in_bytes, const dpx_segment *segs, size_t n_segs);
 int dpx_stream_pending(const dpx_stream *s, int *n_in_flight);

@@ -139,3 +139,152 @@ def test_track_replay_with_tle(orc):
         assert r.returncode == 1 and b"not found" in r.stderr
     finally:
         os.unlink(path)
+
+
+def run_cli_files(args, data, env=None, out_mode="file"):
+    """stdin from a regular file (pread workers) and stdout to a regular file (pwrite workers) or a pipe."""
+    e = dict(os.environ)
+    if env:
+        e.update(env)
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
+        src, dst = os.path.join(d, "in.iq"), os.path.join(d, "out.iq")
+        with open(src, "wb") as f:
+            f.write(bytes(data))
+        with open(src, "rb") as fi:
+            if out_mode == "file":
+                with open(dst, "wb") as fo:
+                    r = subprocess.run([EXE] + args, stdin=fi, stdout=fo, stderr=subprocess.PIPE, timeout=300, env=e)
+                with open(dst, "rb") as fo:
+                    out = fo.read()
+            else:
+                r = subprocess.run([EXE] + args, stdin=fi, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
+                out = r.stdout
+    return r, np.frombuffer(out, dtype=np.uint8)
+
+
+@pytest.mark.parametrize("gpus", [1, 2, 3])
+def test_files_in_and_out_and_several_gpus(orc, gpus):
+    """Regular files on stdin / stdout take the parallel path (slabs filled with pread and drained with pwrite by worker
+    threads, out of order, at the offsets of the sequential loop); --gpus N deals the slabs round-robin over N contexts
+    (here all on device 0: DOPPLER_DEVICES=0,0,...; the code path is the one N real GPUs take).  Same bytes as the oracle's
+    sequential loop, for slabs of one block up to more than the file, exact multiples of the slab size, and an empty file."""
+    rate = 1024000
+    devs = {"DOPPLER_DEVICES": ",".join(["0"] * gpus)}
+    for intype, outtype, n in (("i16", "i16", 2048 * 1500 + 77), ("f32", "i16", 1024 * 64 * 9), ("i16", "f32", 0)):
+        x = make_iq(intype, n, 17 + gpus, full_scale=True)
+        want, _ = orc.const_stream(x, intype, outtype, 5001, rate, threads=4)
+        args = ["const", "-s", str(rate), "-i", intype, "-o", outtype, "--shift", "5001", "--gpus", str(gpus)]
+        for slab, threads in (("65536", "3"), ("8192", "2"), ("1048576", "8"), ("33554432", "1")):
+            env = dict(devs, DOPPLER_SLAB_BYTES=slab, DOPPLER_IO_THREADS=threads, DOPPLER_STATS="1")
+            r, got = run_cli_files(args, x, env)
+            assert r.returncode == 0, r.stderr[-600:]
+            assert b"pread workers in, pwrite workers out" in r.stderr and ("%d GPU(s)" % gpus).encode() in r.stderr
+            assert_same_bytes(got, want, outtype, "%s->%s files, %d gpus, slab %s" % (intype, outtype, gpus, slab))
+        r, got = run_cli_files(args, x, dict(devs, DOPPLER_SLAB_BYTES="131072"), out_mode="pipe")
+        assert r.returncode == 0, r.stderr[-600:]
+        assert_same_bytes(got, want, outtype, "file in, pipe out")
+        r = run_cli(args, x, dict(devs, DOPPLER_SLAB_BYTES="131072"))                 # pipe in, pipe out
+        assert r.returncode == 0, r.stderr[-600:]
+        assert_same_bytes(np.frombuffer(r.stdout, dtype=np.uint8), want, outtype, "pipes, %d gpus" % gpus)
+    # a ragged last block on the file path: complete blocks written, status 101
+    x = make_iq("i16", 2048 * 40 + 3, 9)[: 8192 * 40 + 10]
+    want, _ = orc.const_stream(x[: 8192 * 40], "i16", "i16", 777, 48000)
+    r, got = run_cli_files(["const", "-s", "48000", "-i", "i16", "--shift", "777", "--gpus", str(gpus)], x,
+                           dict(devs, DOPPLER_SLAB_BYTES="65536"))
+    assert r.returncode == 101 and b"assertion failed" in r.stderr
+    assert_same_bytes(got, want, "i16", "complete blocks only (files)")
+
+
+def test_track_replay_over_two_gpus_with_files(orc):
+    """Track replay with the slabs of one stream alternating between two contexts: the per-block schedule and the carried
+    counter live on the host, so the output is the single-GPU one."""
+    rate, freq, off = 256000, 437505000, -1200
+    rr = 6.5 * np.tanh((np.arange(20, dtype=np.float64) - 7.0) / 2.5)
+    n = rate * 13 + 999
+    x = make_iq("i16", n, 23)
+    want, _, _ = orc.track_stream(x, "i16", "f32", rate, freq, rr, offset_hz=off)
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        f.write("\n".join("%.12f" % v for v in rr))
+        path = f.name
+    try:
+        args = ["track", "-s", str(rate), "-i", "i16", "-o", "f32", "--range-rate-file", path, "--frequency", str(freq),
+                "--offset", str(off), "--time", "2015-01-22T09:07:16", "--gpus", "2"]
+        r, got = run_cli_files(args, x, {"DOPPLER_DEVICES": "0,0", "DOPPLER_SLAB_BYTES": "262144", "DOPPLER_IO_THREADS": "3"})
+        assert r.returncode == 0, r.stderr[-600:]
+        assert_same_bytes(got, want, "f32", "track over two contexts")
+    finally:
+        os.unlink(path)
+
+
+def test_status_lines_have_the_reference_format_and_cadence(orc):
+    """N4: every stderr line is fern's format of main.rs:220-223, '{ts}.{ms:3} [{level:<6} {module:<30} {line:>3}]  {msg}',
+    and the replay status block (time / az / el / range / range rate / doppler, main.rs:167-175) appears once per five
+    seconds of STREAM time: at +5 s and +10 s for a 12.5 s stream, with the RFC 3339 time of start + dt."""
+    import re
+    l1 = "1 88888U          80275.98708465  .00073094  13844-3  66816-4 0    87"
+    l2 = "2 88888  72.8435 115.9689 0086731  52.6988 110.5714 16.05824518  1058"
+    rate = 48000
+    n = rate * 12 + rate // 2
+    x = make_iq("i16", n, 4)
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        f.write("TEST SAT 88888\n" + l1 + "\n" + l2 + "\n")
+        path = f.name
+    try:
+        r = run_cli(["track", "-s", str(rate), "-i", "i16", "--tlefile", path, "--tlename", "TEST SAT 88888", "--location",
+                     "lat=58.26541,lon=26.46667,alt=76", "--frequency", "437505000", "--time", "1980-10-01T23:50:00"], x)
+    finally:
+        os.unlink(path)
+    assert r.returncode == 0, r.stderr[-400:]
+    text = r.stderr.decode("utf-8")
+    fern = re.compile(r"^\d{4}-\d\d-\d\dT\d\d:\d\d:\d\d\.[ \d]{3} \[INFO   doppler {24} +\d+\]  ")
+    lines = [ln for ln in text.split("\n") if ln.strip()]
+    starts = [ln for ln in lines if fern.match(ln)]
+    # messages with embedded newlines (the reference's "\n\n" banners) continue on unprefixed EMPTY lines only
+    assert len(starts) == len(lines), [ln for ln in lines if not fern.match(ln)][:3]
+    times = re.findall(r"\]  time                : (\S+)", text)
+    assert times == ["1980-10-01T23:50:05Z", "1980-10-01T23:50:10Z"], times
+    block = re.compile(r"time                : \S+\n[^\n]*az                  : -?\d+\.\d\d°\n[^\n]*el                  : -?\d+\.\d\d°\n"
+                       r"[^\n]*range               : \d+ km\n[^\n]*range rate          : -?\d+\.\d{3} km/sec\n"
+                       r"[^\n]*doppler@437\.505 MHz : -?\d+\.\d\d Hz\n")
+    assert len(block.findall(text)) == 2, text[-1500:]
+
+
+def test_live_track_mode_evaluates_the_orbit_for_every_block(orc):
+    """main.rs:186-205: without --time the reference calls predict.update(None) before EVERY 8192-byte block.  With an
+    injected clock that advances a quarter of a second per query (DOPPLER_FAKE_CLOCK) and a range-rate table, block b
+    must be shifted with the table entry of floor((b + 1) / 4) seconds after start-up — whatever arrives at once."""
+    rate, freq, off = 48000, 437505000, 250
+    rr = np.array([-6.0 + 0.9 * k for k in range(40)], dtype=np.float64)
+    nblocks = 57
+    n = 2048 * nblocks + 100
+    x = make_iq("i16", n, 12)
+    segs = []
+    for b in range(nblocks + 1):
+        dt = int((b + 1) * 0.25)
+        doppler = (rr[min(dt, rr.size - 1)] * 1000.0 / 299792458.0) * float(freq) * (-1.0)
+        hz = float(np.float32(np.float32(doppler) + np.float32(off)))
+        cnt = min(2048, n - b * 2048)
+        segs.append((cnt, hz))
+    want, _ = orc.segments_stream(x, "i16", "i16", segs, rate)
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        f.write("\n".join("%.12f" % v for v in rr))
+        path = f.name
+    try:
+        r = run_cli(["track", "-s", str(rate), "-i", "i16", "--range-rate-file", path, "--frequency", str(freq), "--offset", str(off)],
+                    x, {"DOPPLER_FAKE_CLOCK": "1700000000,0.25"})
+    finally:
+        os.unlink(path)
+    assert r.returncode == 0, r.stderr[-400:]
+    assert_same_bytes(np.frombuffer(r.stdout, dtype=np.uint8), want, "i16", "live mode, one orbit evaluation per block")
+    # once per second of (injected) wall time: 57 blocks x 0.25 s = 14 s
+    assert 12 <= r.stderr.count(b"range rate          :") <= 15
+
+
+def test_write_error_ends_with_the_status_of_a_panic():
+    """main.rs:86-95 unwrap()s the result of stdout.write: a failing write is a panic (status 101), after everything in
+    flight has been wound down (no exit() from a worker thread)."""
+    x = make_iq("i16", 2048 * 300, 5)
+    with open("/dev/full", "wb") as full:
+        r = subprocess.run([EXE, "const", "-s", "1024000", "-i", "i16", "--shift", "5000"], input=bytes(x), stdout=full,
+                           stderr=subprocess.PIPE, timeout=120, env=dict(os.environ, DOPPLER_SLAB_BYTES="65536"))
+    assert r.returncode == 101 and b"stdout.write error" in r.stderr, (r.returncode, r.stderr[-300:])

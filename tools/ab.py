@@ -61,6 +61,7 @@ def cases(which):
             for comp in (0, 1):
                 c.append(("track %d s replay" % secs, lambda f, t=secs: track_segs(t, f), "i16:i16", 3, dict(walk_compute=comp)))
     if which == "final":
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
         for opts in (dict(), dict(walk_waves=5), dict(walk_waves=8), dict(walk_compute=0)):
             c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, opts))
             c.append(("track 300 s replay", lambda f: track_segs(300, f), "f32:i16", 3, opts))
@@ -159,6 +160,10 @@ def main():
             e1.record(stream)
             stream.synchronize()
             b["ms"].append(e0.elapsed_time(e1) / args.iters)
+    ref = None
+    for b in built:
+        if "headline" in b["name"]:
+            ref = statistics.median(b["ms"]) / b["n"]
     for b in built:
         med = statistics.median(b["ms"])
         alg = b["n"] * (BPS[b["it"]] + BPS[b["ot"]])
@@ -167,7 +172,8 @@ def main():
         kern = "walk" if lay["walk_launches"] else ("rows" if lay["rows_launches"] else "tile")
         print(json.dumps({"case": b["name"], "pair": b["pair"], "variant": b["variant"], "opts": b["opts"], "geom": b["geom"], "kernel": kern,
                           "ms_med": round(med, 4), "ms_min": round(min(b["ms"]), 4), "GBps": round(gbs, 1), "pct_peak": round(gbs / 80, 1),
-                          "table_MiB": round(lay["table_entries"] * 8 / 2**20, 1), "single_samples": lay["single_samples"]}), flush=True)
+                          "table_MiB": round(lay["table_entries"] * 8 / 2**20, 1), "single_samples": lay["single_samples"],
+                          "vs_headline": round(ref / (med / b["n"]) * (BPS[b["it"]] + BPS[b["ot"]]) / 8, 4) if ref else None}), flush=True)
 
 
 if __name__ == "__main__":
