@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <new>
 #include <vector>
@@ -322,6 +323,38 @@ int run_host(dpx_ctx *ctx, const void *in, size_t n, int in_fmt, void *out, int 
     return DPX_OK;
 }
 
+// the same for a list of constant-shift segments (host pointers): one plan, one fused launch
+int run_host_segments(dpx_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt, uint32_t *samplenum,
+                      const dpx_segment *segs, size_t n_segs, uint32_t samplerate)
+{
+    DPX_HIP(hipSetDevice(ctx->device));
+    dpx::PlanResult plan;
+    uint32_t sn = *samplenum;
+    append_segments(plan, segs, n_segs, samplerate, sn, ctx->variant, ctx->periods);
+    const uint64_t n = plan.n_samples;
+    if (n == 0) {
+        *samplenum = sn;
+        return DPX_OK;
+    }
+    const dpx::LaunchGeom g = geometry(ctx);
+    dpx::finalize(plan, g.tile(), ctx->choice, ctx->tuning);
+    if (plan.error) return fail(DPX_ERR_PLAN, "%s", plan.error);
+    const size_t in_bytes = n * bytes_per_sample(in_fmt), out_bytes = n * bytes_per_sample(out_fmt);
+    int rc = ensure_stage(ctx, in_bytes, out_bytes);
+    if (rc != DPX_OK) return rc;
+    if (!ctx->scratch) ctx->scratch = new (std::nothrow) DevPlan;
+    if (!ctx->scratch) return fail(DPX_ERR_ARG, "out of host memory");
+    rc = materialize(ctx, plan, *ctx->scratch, ctx->fma, ctx->stream);
+    if (rc != DPX_OK) return rc;
+    DPX_HIP(hipMemcpyAsync(ctx->stage_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = run_plan(plan, *ctx->scratch, ctx->stage_in, in_fmt, ctx->stage_out, out_fmt, ctx->fma, g, ctx->stream);
+    if (rc != DPX_OK) return rc;
+    DPX_HIP(hipMemcpyAsync(out, ctx->stage_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    DPX_HIP(hipStreamSynchronize(ctx->stream));
+    *samplenum = sn;
+    return DPX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -435,6 +468,33 @@ int dpx_shift_block(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt, v
     if (n * bytes_per_sample(out_fmt) > out_cap || (!out && n))
         return fail(DPX_ERR_CAPACITY, "output needs %zu bytes, capacity %zu", n * bytes_per_sample(out_fmt), out_cap);
     int rc = run_host(ctx, in, n, in_fmt, out, out_fmt, samplenum, shift_hz, samplerate);
+    if (rc == DPX_OK && n_samples_out) *n_samples_out = n;
+    return rc;
+}
+
+int dpx_shift_blocks(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt, void *out, size_t out_cap, int out_fmt,
+                     uint32_t *samplenum, const float *shift_hz, size_t n_blocks, uint32_t samplerate, size_t *n_samples_out)
+{
+    if (!ctx || !samplenum || (!in && in_bytes) || !fmt_ok(in_fmt) || !fmt_ok(out_fmt) || (n_blocks && !shift_hz))
+        return fail(DPX_ERR_ARG, "bad argument");
+    const size_t ibs = bytes_per_sample(in_fmt);
+    if (n_blocks != (in_bytes + DPX_BUFFER_SIZE - 1) / DPX_BUFFER_SIZE)
+        return fail(DPX_ERR_ARG, "%zu bytes are %zu blocks of %d bytes, not %zu", in_bytes, (in_bytes + DPX_BUFFER_SIZE - 1) / DPX_BUFFER_SIZE,
+                    DPX_BUFFER_SIZE, n_blocks);
+    if (in_bytes % ibs != 0)
+        return fail(DPX_ERR_BLOCK_LEN, "%zu bytes is not a whole number of %s samples", in_bytes, in_fmt == DPX_FMT_I16 ? "i16" : "f32");
+    const size_t n = in_bytes / ibs;
+    if (n * bytes_per_sample(out_fmt) > out_cap || (!out && n))
+        return fail(DPX_ERR_CAPACITY, "output needs %zu bytes, capacity %zu", n * bytes_per_sample(out_fmt), out_cap);
+    // runs of blocks with the same shift (bit pattern) become one segment: same arithmetic, fewer stretches
+    std::vector<dpx_segment> segs;
+    const size_t spb = DPX_BUFFER_SIZE / ibs;
+    for (size_t b = 0; b < n_blocks; ++b) {
+        const uint64_t cnt = std::min<uint64_t>(spb, n - b * spb);
+        if (!segs.empty() && memcmp(&segs.back().shift_hz, &shift_hz[b], sizeof(float)) == 0) segs.back().n_samples += cnt;
+        else segs.push_back({cnt, shift_hz[b]});
+    }
+    int rc = run_host_segments(ctx, in, in_fmt, out, out_fmt, samplenum, segs.data(), segs.size(), samplerate);
     if (rc == DPX_OK && n_samples_out) *n_samples_out = n;
     return rc;
 }

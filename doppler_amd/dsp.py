@@ -83,6 +83,20 @@ def shift_block(inbytes, intype, outtype, samplenum, shift_hz, samplerate, ctx=N
     return out[: n.value * BYTES_PER_SAMPLE[ot]], n.value, sn.value
 
 
+def shift_blocks(inbytes, intype, outtype, samplenum, shift_hz_per_block, samplerate, ctx=None):
+    """Many 8192-byte blocks in one call, one shift per block (dpx_shift_blocks). Returns (out_bytes, n_samples, samplenum)."""
+    ctx = _ctx(ctx)
+    b = as_bytes(inbytes)
+    it, ot = fmt_code(intype), fmt_code(outtype)
+    hz = np.ascontiguousarray(shift_hz_per_block, dtype=np.float32)
+    out = np.empty(b.size // BYTES_PER_SAMPLE[it] * BYTES_PER_SAMPLE[ot] + 8, dtype=np.uint8)
+    sn = C.c_uint32(samplenum)
+    n = C.c_size_t()
+    check(ctx._lib.dpx_shift_blocks(ctx.handle, b.ctypes.data, b.size, it, out.ctypes.data, out.size, ot, C.byref(sn),
+                                    hz.ctypes.data, hz.size, int(samplerate), C.byref(n)))
+    return out[: n.value * BYTES_PER_SAMPLE[ot]], n.value, sn.value
+
+
 def ccexpf(z, ctx=None):
     """src/complex.c:33-39: cexpf(z.re + i*z.im) for each element (returned; the C function works in place)."""
     ctx = _ctx(ctx)

@@ -178,8 +178,12 @@ def test_files_in_and_out_and_several_gpus(orc, gpus):
             env = dict(devs, DOPPLER_SLAB_BYTES=slab, DOPPLER_IO_THREADS=threads, DOPPLER_STATS="1")
             r, got = run_cli_files(args, x, env)
             assert r.returncode == 0, r.stderr[-600:]
-            assert b"pread workers in, pwrite workers out" in r.stderr and ("%d GPU(s)" % gpus).encode() in r.stderr
+            assert (b"pread workers in, mapped-file workers out" in r.stderr or (n == 0 and b"pread workers in, pwrite workers out" in r.stderr)) \
+                and ("%d GPU(s)" % gpus).encode() in r.stderr
             assert_same_bytes(got, want, outtype, "%s->%s files, %d gpus, slab %s" % (intype, outtype, gpus, slab))
+        r, got = run_cli_files(args, x, dict(devs, DOPPLER_SLAB_BYTES="65536", DOPPLER_NO_MMAP="1"))      # pwrite workers instead of the mapping
+        assert r.returncode == 0 and b"pwrite workers out" in r.stderr, r.stderr[-600:]
+        assert_same_bytes(got, want, outtype, "files, pwrite workers")
         r, got = run_cli_files(args, x, dict(devs, DOPPLER_SLAB_BYTES="131072"), out_mode="pipe")
         assert r.returncode == 0, r.stderr[-600:]
         assert_same_bytes(got, want, outtype, "file in, pipe out")

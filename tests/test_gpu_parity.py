@@ -195,6 +195,29 @@ def test_operator_functions_match_reference_semantics(ctx, orc):
     assert o.size == 0 and cnt == 0 and sn2 == 5
 
 
+def test_shift_blocks_batches_the_reference_loop(ctx, orc):
+    """dpx_shift_blocks: N reference blocks per call with one shift per block (what the track loop of main.rs:160-183
+    produces), counter carried through the blocks and across calls — equal to the golden track replay block by block,
+    for batch sizes 1, 7 and 64, and to N single-block calls."""
+    from doppler_amd import dsp
+    t = load_golden("track_stream_case.npz")
+    rate, _, _, sn_final = t["meta"]
+    x, log = t["x"], t["shift_log"]
+    nblocks = (x.size + 8191) // 8192
+    for batch in (1, 7, 64):
+        outs, sn = [], 0
+        for b0 in range(0, nblocks, batch):
+            b1 = min(nblocks, b0 + batch)
+            o, cnt, sn = dsp.shift_blocks(x[b0 * 8192:b1 * 8192], "i16", "i16", sn, log[b0:b1], int(rate), ctx=ctx)
+            outs.append(o)
+        assert sn == int(sn_final)
+        assert_same_bytes(np.concatenate(outs), t["y"], "i16", "shift_blocks, %d blocks per call" % batch)
+    with pytest.raises(dsp.DspError):
+        dsp.shift_blocks(x[: 8192 * 3], "i16", "i16", 0, log[:2], int(rate), ctx=ctx)       # 3 blocks, 2 shifts
+    o, cnt, sn = dsp.shift_blocks(np.zeros(0, np.uint8), "f32", "i16", 9, np.zeros(0, np.float32), 1000, ctx=ctx)
+    assert o.size == 0 and cnt == 0 and sn == 9
+
+
 def test_reference_bench_configuration_on_device(ctx):
     """src/dsp.rs:136-157: 1 000 000 bytes of 0xAA as f32 IQ, 815 kHz at 2.4 Msps, counter carried over 301 calls."""
     from doppler_amd import dsp

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): rocprofv3 kernel-trace stats and the two HBM-traffic PMC passes for the bench
+# command (headline and track workloads), plus a calibration pass on the plain copy kernel; the summaries
+# (gpurun_out/r02_*.md / .json, small) are what comes back — copy them into profiles/.
+set -u
+REPO=$PWD
+OUT=/tmp/prof_r02
+rm -rf $OUT; mkdir -p $OUT $REPO/gpurun_out
+export TMPDIR=/tmp
+cd /tmp
+for wl in const track; do
+  CMD="python $REPO/bench.py --workload $wl --steps 20 --warmup 5 --no-cpu --no-extra"
+  rocprofv3 --kernel-trace --stats -d $OUT/${wl}_trace -o bench -- $CMD > $OUT/${wl}_trace.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${wl}_fetch -o bench -- $CMD > $OUT/${wl}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${wl}_write -o bench -- $CMD > $OUT/${wl}_write.log 2>&1
+done
+# calibration: a copy of known size through dpx_debug_copy (1 GiB read, 1 GiB written)
+CAL="python $REPO/tools/sweep.py --iters 5 --variants 4 --geoms 256x1"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cal_fetch -o cal -- $CAL > $OUT/cal_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cal_write -o cal -- $CAL > $OUT/cal_write.log 2>&1
+cd $REPO
+grep -h "^{" $OUT/const_trace.log | tail -1 > gpurun_out/r02_bench_line_under_rocprof.json
+grep -h "^{" $OUT/track_trace.log | tail -1 > gpurun_out/r02_bench_line_track_under_rocprof.json
+python tools/summarize_r02.py $OUT gpurun_out

@@ -1,0 +1,93 @@
+"""Turn the rocprofv3 databases written by tools/profile_r02.sh into the summaries committed under profiles/.
+
+    python tools/summarize_r02.py /tmp/prof_r02 gpurun_out
+writes <out>/r02_rocprof_kernel_stats.md and <out>/r02_pmc_traffic.json (with the hash of the kernel sources, which
+bench.py checks before quoting any of it).
+"""
+import glob
+import json
+import os
+import re
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name).replace("void ", "")
+    return name if len(name) < 90 else name[:87] + "..."
+
+
+def db_of(d):
+    f = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+    return f[0] if f else None
+
+
+def kernel_stats(db_path):
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select name, count(*), avg(duration), min(duration), max(duration), sum(duration) "
+                      "from kernels group by name order by sum(duration) desc").fetchall()
+    return [(short(n), c, a / 1e3, mn / 1e3, mx / 1e3, t / 1e3) for n, c, a, mn, mx, t in rows]
+
+
+def counter(db_path, name):
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name",
+                      (name,)).fetchall()
+    return {short(n): (c, a) for n, c, a in rows}
+
+
+def main():
+    src, out = sys.argv[1], sys.argv[2]
+    import bench
+    lines = ["# Round 2 — rocprofv3 --kernel-trace --stats and HBM-traffic counters (1x MI355X, `tools/profile_r02.sh`)", "",
+             "Commands: `python bench.py --workload const|track --steps 20 --warmup 5 --no-cpu --no-extra`; kernel sources sha "
+             "`%s`." % bench.kernel_source_sha(), ""]
+    result = {"kernel_source_sha": bench.kernel_source_sha()}
+    # calibration of the counters on a copy of known size
+    cal_f = counter(db_of(os.path.join(src, "cal_fetch")), "FETCH_SIZE")
+    cal_w = counter(db_of(os.path.join(src, "cal_write")), "WRITE_SIZE")
+    ck = [k for k in cal_f if "copy_kernel" in k]
+    fscale = wscale = None
+    if ck:
+        fscale = (1 << 30) / (cal_f[ck[0]][1] * 1024.0)
+        wscale = (1 << 30) / (cal_w[ck[0]][1] * 1024.0)
+        lines += ["Calibration on `dpx::copy_kernel` (1 GiB read + 1 GiB written): FETCH_SIZE x %.4f, WRITE_SIZE x %.4f "
+                  "(the guide's gfx950 note: FETCH_SIZE reports half the bytes of a wide streaming read)." % (fscale, wscale), ""]
+    for wl, pat, alg in (("const", "rows_kernel", 268435456 * 8), ("track", "walk_kernel", 614400000 * 8)):
+        stats = kernel_stats(db_of(os.path.join(src, wl + "_trace")))
+        lines += ["## %s workload" % wl, "", "| kernel | calls | avg us | min us | max us | total us |", "|---|---|---|---|---|---|"]
+        for n, c, a, mn, mx, t in stats[:6]:
+            lines.append("| `%s` | %d | %.3f | %.3f | %.3f | %.1f |" % (n, c, a, mn, mx, t))
+        main_k = [s for s in stats if pat in s[0]]
+        r = {"algorithmic_bytes_per_launch": alg}
+        if main_k:
+            n, c, a, mn, mx, t = main_k[0]
+            r["kernel"] = n
+            r["avg_launch_us_kernel_trace"] = round(a, 3)
+            r["launches"] = c
+            lines += ["", "Dominant kernel `%s`: average %.3f us over %d launches (warm-up included) -> %.1f GB/s algorithmic "
+                      "(%d B per launch) = %.1f %% of the 8.0 TB/s HBM3E peak." % (n, a, c, alg / a / 1e3, alg, alg / a / 1e3 / 80.0)]
+        f = counter(db_of(os.path.join(src, wl + "_fetch")), "FETCH_SIZE")
+        w = counter(db_of(os.path.join(src, wl + "_write")), "WRITE_SIZE")
+        fk = [k for k in f if pat in k]
+        if fk and fscale:
+            rd = f[fk[0]][1] * 1024.0 * fscale
+            wr = w[fk[0]][1] * 1024.0 * wscale
+            r.update(fetch_size_raw_kib=round(f[fk[0]][1], 1), write_size_raw_kib=round(w[fk[0]][1], 1), fetch_scale=fscale, write_scale=wscale,
+                     hbm_read_bytes_per_launch=int(rd), hbm_write_bytes_per_launch=int(wr), hbm_bytes_per_launch=int(rd + wr))
+            lines += ["", "HBM traffic per launch (separate --pmc passes, calibrated): %.1f MiB read + %.1f MiB written = %.1f MiB "
+                      "against %.1f MiB algorithmic: ratio %.4f (reads alone against the input bytes: %.4f)." %
+                      (rd / 2**20, wr / 2**20, (rd + wr) / 2**20, alg / 2**20, (rd + wr) / alg, rd / (alg / 2)), ""]
+        result[wl] = r
+    with open(os.path.join(out, "r02_rocprof_kernel_stats.md"), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    with open(os.path.join(out, "r02_pmc_traffic.json"), "w") as fh:
+        json.dump(result, fh, indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
