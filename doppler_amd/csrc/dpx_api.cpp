@@ -401,6 +401,14 @@ int dpx_ctx_create(int device, dpx_ctx **out)
         delete ctx;
         return fail(DPX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
     }
+    // Load the kernels' code object now (the HIP runtime does it at the first launch, ~8 ms): a first plan or a first
+    // 8 KiB block should not pay for it.  A 16-byte copy inside a scratch allocation is the cheapest launch there is.
+    void *warm = nullptr;
+    if (hipMalloc(&warm, 64) == hipSuccess) {
+        (void)dpx::launch_copy(warm, static_cast<char *>(warm) + 32, 16, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(warm);
+    }
     *out = ctx;
     return DPX_OK;
 }

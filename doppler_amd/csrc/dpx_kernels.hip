@@ -359,13 +359,17 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
         uint32_t base;   // periodic: phase of t0 in [0, P); linear: the counter itself
         if (P != 0) base = (uint32_t)(((uint64_t)(sg.n_start - 1u) + j0) % P);
         else        base = sg.n_start + (uint32_t)j0;
+        // whether the counter wraps inside this tile is the same for all its lanes (base is the tile's): almost every
+        // tile takes the path with one addition per counter
+        const bool wraps = P != 0 && base + TILE > P;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             uint32_t t = base + (uint32_t)(v * BLOCK + tid) * SPL;     // periodic: < P + TILE
             uint32_t n[SPL];
-            if (P == 0) {
+            if (!wraps) {
+                const uint32_t n0 = P == 0 ? t : t + 1u;                // u32 arithmetic wraps like the reference's `+= 1`
 #pragma unroll
-                for (int k = 0; k < (int)SPL; ++k) n[k] = t + k;         // u32 arithmetic wraps like the reference's `+= 1`
+                for (int k = 0; k < (int)SPL; ++k) n[k] = n0 + k;
             } else {
                 if (P >= TILE) t = t >= P ? t - P : t;                   // at most one wrap (uniform branch)
                 else           t %= P;
