@@ -628,9 +628,6 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
         }
     } else {
         // ---- leftover ranges: one block of kLeftBlock samples of ONE stretch, sincos per sample
-#ifdef DPX_DEBUG_SKIP_LEFT      // timing experiments only (wrong output): what the leftover workgroups cost
-        return;
-#endif
         const uint32_t e = ws.row0 + w;                           // index of this block among all leftover blocks
         uint32_t li = lhint[e >> kLeftHintShift];
         while (left[li + 1].wg_off <= e) ++li;                    // sentinel at the end
