@@ -419,6 +419,13 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
 template <int IN_FMT, int OUT_FMT> struct WalkVec {
     static constexpr int S = RowVec<IN_FMT, OUT_FMT>::S;
     static constexpr bool kTranspose = IN_FMT == DPX_FMT_F32 && OUT_FMT == DPX_FMT_I16;
+    // f32 output: a 256-sample window is 2 KiB per row on the wide side — two vectors per lane per row, which measures
+    // 8 points below one (75 % against 83 % of the HBM peak for the same stream on the rows kernel, which moves one
+    // vector per lane per row).  Such a window is therefore shared by TWO workgroups, 128 columns each (the grid is
+    // doubled at launch; the plan, which does not know the formats, is unchanged).
+    static constexpr int kSplit = (S == 2 && !kTranspose) ? 2 : 1;
+    static constexpr uint32_t kCols = kWalkWindow / kSplit;              // columns a workgroup takes
+    static constexpr uint32_t kEntries = kCols + kWalkPad;               // slice entries it needs
 };
 
 // LDS layout of a slice: S planes by entry index modulo S (entry e at plane e % S, position e / S): the S correctors a
@@ -435,11 +442,14 @@ template <int S> struct SlicePlanes {
 // everything a wavefront does for its U rows of window w (after the descriptor and, in table mode, the slice loads)
 template <int IN_FMT, int OUT_FMT, bool FMA, int WAVES, int U, int TL>
 __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint8_t *__restrict__ sink,
-                                          const WalkSeg &ws, uint32_t w, uint32_t wave, uint32_t lane, uint32_t tid, bool compute,
+                                          const WalkSeg &ws, uint32_t w, uint32_t half, uint32_t wave, uint32_t lane, uint32_t tid, bool compute,
                                           const float2 (&t0)[TL], const float2 (&t1)[TL], float2 *slice, uint32_t *xpose)
 {
     constexpr int S = WalkVec<IN_FMT, OUT_FMT>::S;                // samples per lane per vector: 4 or 2
-    constexpr int NV = (int)kWalkWindow / (kRowsLanes * S);       // vectors per lane per row: 1 or 2
+    typedef WalkVec<IN_FMT, OUT_FMT> WV;
+    constexpr int NV = (int)WV::kCols / (kRowsLanes * S);         // vectors per lane per row: 1 (2 for f32 -> i16)
+    constexpr uint32_t kEntries = WV::kEntries;                   // 288, or 160 for half a window
+    const uint32_t col0 = w * kWalkWindow + half * WV::kCols;     // first column of this workgroup
     constexpr int THREADS = WAVES * 64;
     constexpr int IB = Fmt<IN_FMT>::kBytes, OB = Fmt<OUT_FMT>::kBytes;
     constexpr int QW = S * IB / 4;                                // input dwords per vector
@@ -455,7 +465,7 @@ __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_
     // with row counts that leave 1..WAVES-1 wavefronts without rows.
     // Measured alternative (profiles/r02_walk.md): only the wavefronts WITH rows evaluate the slice, so that the others
     // leave at once — slower everywhere (the serial evaluations delay the surviving wavefronts past their loads).
-    const uint32_t slice_threads = compute ? kWalkSlice : kWalkSlice / 2;
+    const uint32_t slice_threads = compute ? kEntries : kEntries / 2;
     if (r0 >= ws.row_end && wave * kRowsLanes >= slice_threads) return;
     qvec qin[U][NV];
     uint32_t off[U];                                          // slice entry of the row's column 0 (uniform per wavefront)
@@ -472,14 +482,14 @@ __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const uint32_t cl = lane * S + (uint32_t)v * (kRowsLanes * S);   // column inside the window
-            const uint32_t c = w * kWalkWindow + cl;
+            const uint32_t c = col0 + cl;
             const bool active = c < rowlen;
             const uint64_t g = active ? row0 + c : ws.A + cl;
             qin[u][v] = __builtin_nontemporal_load(reinterpret_cast<const qvec *>(in + g * IB));
             op[u][v] = active ? out + g * OB : sink + tid * 16;
         }
         off[u] = kWalkPad - delta;
-        const uint32_t c4 = w * kWalkWindow + lane * 4;
+        const uint32_t c4 = col0 + lane * 4;
         opx[u] = c4 < rowlen ? out + (row0 + c4) * OB : sink + tid * 16;
     }
 
@@ -488,8 +498,8 @@ __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_
         // loads above have been issued, so the evaluation runs in the shadow of the HBM latency
         const uint32_t P = ws.period;
         // counter of column c: ((phase + c) mod P) + 1, c = 256 w + j - kWalkPad >= -kWalkPad
-        const uint32_t ub = ws.phase + w * kWalkWindow;       // < period + L + 255 < 2^24
-        for (uint32_t j = tid; j < kWalkSlice; j += THREADS) {
+        const uint32_t ub = ws.phase + col0;                  // < period + L + 255 < 2^24
+        for (uint32_t j = tid; j < kEntries; j += THREADS) {
             uint32_t t;
             if (ws.L == P) {                                  // P >= kWalkMinL > kWalkPad: at most two wraps
                 t = ub + j + P - kWalkPad;
@@ -507,7 +517,7 @@ __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_
 #pragma unroll
         for (int i = 0; i < TL; ++i) {
             const uint32_t j = tid + (uint32_t)i * THREADS;
-            if (j < kWalkSlice / 2) {                           // entries 2j and 2j + 1
+            if (j < kEntries / 2) {                             // entries 2j and 2j + 1
                 slice[SP::index(2 * j)] = t0[i];
                 slice[SP::index(2 * j + 1)] = t1[i];
             }
@@ -591,7 +601,8 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
     // matrix (replicated per group; chunks start on multiples of 8 workgroups) or a group of leftover blocks.  The
     // leftover groups (sincos per sample, VALU-bound) are spread evenly between the chunks by the planner, so that they
     // run beside memory-bound workgroups.
-    const uint32_t b = blockIdx.x;
+    constexpr uint32_t kSplit = WalkVec<IN_FMT, OUT_FMT>::kSplit;     // workgroups per window (grid scaled at launch)
+    const uint32_t b = blockIdx.x / kSplit, half = blockIdx.x % kSplit;
     const WalkSeg ws = wdesc[b >> kWalkHintShift];
     const uint32_t w = b - ws.wg_base;
     if (w >= ws.nw) return;                                       // padding
@@ -601,7 +612,8 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
 
         // this window's slice of correctors: entry j = corrector of column 256 w + j - kWalkPad; in table mode it comes
         // from the plan-time table, 16 bytes per thread, requested before the samples
-        constexpr int TL = ((int)kWalkSlice / 2 + THREADS - 1) / THREADS;   // 16-byte pieces per thread: 1 (2 for 128 threads)
+        constexpr uint32_t kEntries = WalkVec<IN_FMT, OUT_FMT>::kEntries;
+        constexpr int TL = ((int)kEntries / 2 + THREADS - 1) / THREADS;     // 16-byte pieces per thread: 1
         // Where the slice comes from is decided per matrix by the planner (WalkSeg::tab_off): evaluated here by the
         // workgroup (no table, no table traffic: matrices of few rows, whose table entries would each be used only a few
         // times), or read from the plan-time table (matrices of many rows: the table is fetched from HBM by the first
@@ -609,11 +621,11 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
         const bool compute = ws.tab_off == kWalkNoTable;
         float2 t0[TL], t1[TL];
         if (!compute) {
-            const float2 *tab = lut_pool + ws.tab_off + w * kWalkWindow;
+            const float2 *tab = lut_pool + ws.tab_off + w * kWalkWindow + half * WalkVec<IN_FMT, OUT_FMT>::kCols;
 #pragma unroll
             for (int i = 0; i < TL; ++i) {
                 const uint32_t j = tid + (uint32_t)i * THREADS;
-                if (j < kWalkSlice / 2) {
+                if (j < kEntries / 2) {
                     t0[i] = tab[2 * j];
                     t1[i] = tab[2 * j + 1];
                 }
@@ -621,13 +633,14 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
         }
         // rows per wavefront of this chunk: uniform for the workgroup
         switch (ws.upw) {
-        case 1:  walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 1, TL>(in, out, sink, ws, w, wave, lane, tid, compute, t0, t1, slice, xpose); break;
-        case 2:  walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 2, TL>(in, out, sink, ws, w, wave, lane, tid, compute, t0, t1, slice, xpose); break;
-        case 3:  walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 3, TL>(in, out, sink, ws, w, wave, lane, tid, compute, t0, t1, slice, xpose); break;
-        default: walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 4, TL>(in, out, sink, ws, w, wave, lane, tid, compute, t0, t1, slice, xpose); break;
+        case 1:  walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 1, TL>(in, out, sink, ws, w, half, wave, lane, tid, compute, t0, t1, slice, xpose); break;
+        case 2:  walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 2, TL>(in, out, sink, ws, w, half, wave, lane, tid, compute, t0, t1, slice, xpose); break;
+        case 3:  walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 3, TL>(in, out, sink, ws, w, half, wave, lane, tid, compute, t0, t1, slice, xpose); break;
+        default: walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 4, TL>(in, out, sink, ws, w, half, wave, lane, tid, compute, t0, t1, slice, xpose); break;
         }
     } else {
         // ---- leftover ranges: one block of kLeftBlock samples of ONE stretch, sincos per sample
+        if (half != 0) return;                                    // a leftover block is one workgroup whatever the grid scaling
         const uint32_t e = ws.row0 + w;                           // index of this block among all leftover blocks
         uint32_t li = lhint[e >> kLeftHintShift];
         while (left[li + 1].wg_off <= e) ++li;                    // sentinel at the end
@@ -873,7 +886,8 @@ static int walk_t(const void *d_in, void *d_out, const DevSeg *d_segs, const voi
     uint8_t *out = static_cast<uint8_t *>(d_out);
     uint8_t *sink = static_cast<uint8_t *>(d_sink);
     const float2 *lut = static_cast<const float2 *>(d_lut);
-    const uint64_t n_wg = w.n_walk_wg;            // the whole grid: row chunks and the groups of leftover blocks between them
+    // the whole grid: row chunks and the groups of leftover blocks between them; x2 where a window is shared by two workgroups
+    const uint64_t n_wg = (uint64_t)w.n_walk_wg * WalkVec<IN_FMT, OUT_FMT>::kSplit;
     if (n_wg == 0) return DPX_OK;
     if (n_wg > 0x7fffffffull) return DPX_ERR_ARG;
     const dim3 grid((uint32_t)n_wg);

@@ -60,6 +60,18 @@ def cases(which):
         for secs in (150, 262, 600):
             for comp in (0, 1):
                 c.append(("track %d s replay" % secs, lambda f, t=secs: track_segs(t, f), "i16:i16", 3, dict(walk_compute=comp)))
+    if which == "f32":
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for pair in ("f32:f32", "i16:f32", "f32:i16", "i16:i16"):
+            c.append(("const 5001 Hz", lambda f: const_segs(5001), pair, 3, {}))
+            c.append(("const 100 Hz", lambda f: const_segs(100), pair, 5, {}))
+            c.append(("track 300 s replay", lambda f: track_segs(300, f), pair, 3, {}))
+    if which == "route":
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for shift, rate in ((100, RATE), (9876.543, RATE), (815000, 2400000), (3, RATE), (5000, RATE), (2500, RATE), (1000, RATE), (15000, 256000)):
+            for pair in ("i16:i16", "f32:f32"):
+                for variant in (6, 5):
+                    c.append(("const %g Hz @%d" % (shift, rate), lambda f, s=shift: const_segs(s), pair, variant, dict(_rate=rate)))
     if which == "final":
         c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
         for opts in (dict(), dict(walk_waves=5), dict(walk_waves=8), dict(walk_compute=0)):
@@ -114,7 +126,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
@@ -133,10 +145,11 @@ def main():
         n = sum(c for c, _ in segs)
         opts = dict(opts)
         block, vecs = opts.pop("_geom", (128, 2))
+        rate = opts.pop("_rate", RATE)
         ctx.set_tuning(block, vecs, variant)
         ctx.set_options(**opts)
-        plan = ctx.plan_segments(segs, RATE)
-        lay = doppler_amd.plan_layout(segs, RATE, 0, block, vecs, variant, options=opts)
+        plan = ctx.plan_segments(segs, rate)
+        lay = doppler_amd.plan_layout(segs, rate, 0, block, vecs, variant, options=opts)
         if (it, "in", n) not in bufs:
             bufs[(it, "in", n)] = (torch.randint(-23170, 23171, (2 * n,), dtype=torch.int16, device=dev) if it == "i16"
                                    else torch.rand(2 * n, dtype=torch.float32, device=dev) * 2 - 1)

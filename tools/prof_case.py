@@ -17,18 +17,20 @@ kv = dict(a.split("=") for a in sys.argv[2:])
 pair = kv.pop("pair", "i16:i16")
 variant = int(kv.pop("variant", 3))
 iters = int(kv.pop("iters", 6))
+RATE = int(kv.pop("rate", RATE))
+geom = kv.pop("geom", None)
 it, ot = pair.split(":")
 if case == "track600":
     segs = bench.track_segments(600, RATE, it, calendar.timegm((2015, 1, 22, 19, 48, 0)))
 elif case == "track300f":
     segs = bench.track_segments(300, RATE, it, calendar.timegm((2015, 1, 22, 19, 48, 0)))
 elif case.startswith("const"):
-    segs = [(268435456, float(case[5:]))]
+    segs = [(int(kv.pop("n", 268435456)), float(case[5:]))]
 else:
     raise SystemExit("unknown case")
 n = sum(c for c, _ in segs)
 ctx = doppler_amd.Context(0)
-ctx.set_tuning(0, 0, variant)
+ctx.set_tuning(*([int(t) for t in geom.split("x")] if geom else [0, 0]), variant)
 ctx.set_options(**{k: int(v) for k, v in kv.items()})
 plan = ctx.plan_segments(segs, RATE)
 dev = torch.device("cuda:0")
