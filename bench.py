@@ -138,6 +138,17 @@ def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True):
 
     for _ in range(warmup):
         plan.run(x.data_ptr(), it, out.data_ptr(), ot, stream.cuda_stream)
+    settle_ms = 0.0
+    if not emit:
+        # Riding along after the headline (`extra`): the K launches of this kernel last ~20 ms, and the chip needs 50-100 ms
+        # under load to settle its clocks (profiles/r02_walk.md) — launch untimed for 150 ms first, so that the figure is the
+        # steady-state one that `bench.py --workload track` (300 steps by default) reports.
+        t_s = time.perf_counter()
+        while time.perf_counter() - t_s < 0.15:
+            for _ in range(10):
+                plan.run(x.data_ptr(), it, out.data_ptr(), ot, stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+        settle_ms = (time.perf_counter() - t_s) * 1e3
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
@@ -169,7 +180,7 @@ def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True):
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": name, "samples_total": total, "samples_per_gpu": n, "segments_total": len(segs),
                        "segments_this_rank": len(inside), "plan_ms": round(plan_ms, 2), "one_shot_ms": round(one_shot_ms, 2),
-                       "in": it, "out": ot},
+                       "in": it, "out": ot, "untimed_settling_ms": round(settle_ms, 1)},
             "roofline": roof,
         }
         if emit:
