@@ -362,15 +362,21 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
         // whether the counter wraps inside this tile is the same for all its lanes (base is the tile's): almost every
         // tile takes the path with one addition per counter
         const bool wraps = P != 0 && base + TILE > P;
+        const bool small = base < (1u << 24) - TILE - 1u;                 // fl32(n0 + k) = fl32(n0) + k for the whole tile
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             uint32_t t = base + (uint32_t)(v * BLOCK + tid) * SPL;     // periodic: < P + TILE
-            uint32_t n[SPL];
+            f32x2 cs[SPL];
             if (!wraps) {
                 const uint32_t n0 = P == 0 ? t : t + 1u;                // u32 arithmetic wraps like the reference's `+= 1`
-#pragma unroll
-                for (int k = 0; k < (int)SPL; ++k) n[k] = n0 + k;
+                if (small) {                                             // every counter of the tile below 2^24 (uniform)
+                    corrector4_consecutive<FMA>(sg.ratio, n0, cs);
+                } else {
+                    const uint32_t n[SPL] = {n0, n0 + 1u, n0 + 2u, n0 + 3u};
+                    corrector4<FMA>(sg.ratio, n, cs);
+                }
             } else {
+                uint32_t n[SPL];
                 if (P >= TILE) t = t >= P ? t - P : t;                   // at most one wrap (uniform branch)
                 else           t %= P;
 #pragma unroll
@@ -378,9 +384,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
                     const uint32_t e = t + k;                            // P >= 4: at most one wrap
                     n[k] = (e >= P ? e - P : e) + 1u;
                 }
+                corrector4<FMA>(sg.ratio, n, cs);
             }
-            f32x2 cs[SPL];
-            corrector4<FMA>(sg.ratio, n, cs);
             Quad<OUT_FMT> qo;
 #pragma unroll
             for (int k = 0; k < (int)SPL; ++k) {
@@ -664,22 +669,27 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
             u32x4_u qv[Fmt<IN_FMT>::kVecs];
 #pragma unroll
             for (int i = 0; i < Fmt<IN_FMT>::kVecs; ++i) qv[i] = *(reinterpret_cast<const u32x4_u *>(in + g * IB) + i);
-            uint32_t n[4];
-            uint32_t t = base + tid * 4u;
-            if (P == 0) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) n[k] = t + k;
-            } else {
-                if (P >= kLeftBlock) t = t >= P ? t - P : t;          // base < P: at most one wrap
-                else                 t %= P;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t ee = t + k;                      // P >= 4: at most one wrap
-                    n[k] = (ee >= P ? ee - P : ee) + 1u;
-                }
-            }
             f32x2 cs[4];
-            corrector4<FMA>(sg.ratio, n, cs);
+            uint32_t t = base + tid * 4u;
+            if ((P == 0 || base + kLeftBlock <= P) && base < (1u << 24) - kLeftBlock - 1u) {
+                // no wrap inside the block and every counter below 2^24 (uniform): the usual case, lead-ins above all
+                corrector4_consecutive<FMA>(sg.ratio, P == 0 ? t : t + 1u, cs);
+            } else {
+                uint32_t n[4];
+                if (P == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) n[k] = t + k;
+                } else {
+                    if (P >= kLeftBlock) t = t >= P ? t - P : t;      // base < P: at most one wrap
+                    else                 t %= P;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t ee = t + k;                  // P >= 4: at most one wrap
+                        n[k] = (ee >= P ? ee - P : ee) + 1u;
+                    }
+                }
+                corrector4<FMA>(sg.ratio, n, cs);
+            }
             Quad<IN_FMT> qi;
 #pragma unroll
             for (int i = 0; i < Fmt<IN_FMT>::kVecs; ++i) qi.v[i] = qv[i];

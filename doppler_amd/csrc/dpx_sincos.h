@@ -336,10 +336,29 @@ __device__ __forceinline__ void corrector(float ratio, uint32_t n, float &c, flo
 // are independent instruction streams for the scheduler.  cs[k] = (cos, sin) for counter n[k].
 typedef float sc_f32x2 __attribute__((ext_vector_type(2)));
 template <bool FMA>
+__device__ __forceinline__ void corrector4_f(float ratio, sc_f32x2 f01, sc_f32x2 f23, sc_f32x2 cs[4]);
+
+template <bool FMA>
 __device__ __forceinline__ void corrector4(float ratio, const uint32_t n[4], sc_f32x2 cs[4])
 {
+    corrector4_f<FMA>(ratio, sc_f32x2{(float)n[0], (float)n[1]}, sc_f32x2{(float)n[2], (float)n[3]}, cs);
+}
+
+// Four CONSECUTIVE counters n0 .. n0 + 3, all below 2^24 (the caller's uniform test): fl32(n0 + k) = fl32(n0) + k exactly,
+// so one conversion and two packed additions replace four conversions and three integer additions.
+template <bool FMA>
+__device__ __forceinline__ void corrector4_consecutive(float ratio, uint32_t n0, sc_f32x2 cs[4])
+{
+    const float f0 = (float)n0;
+    corrector4_f<FMA>(ratio, sc_f32x2{f0, f0} + sc_f32x2{0.0f, 1.0f}, sc_f32x2{f0, f0} + sc_f32x2{2.0f, 3.0f}, cs);
+}
+
+// fl32 of the four counters given: the two f32 products of theta, then the path decision
+template <bool FMA>
+__device__ __forceinline__ void corrector4_f(float ratio, sc_f32x2 f01, sc_f32x2 f23, sc_f32x2 cs[4])
+{
     const sc_f32x2 r2 = {ratio, ratio}, m2 = {-6.28318530717958647692f, -6.28318530717958647692f};
-    const sc_f32x2 p01 = sc_f32x2{(float)n[0], (float)n[1]} * r2, p23 = sc_f32x2{(float)n[2], (float)n[3]} * r2;
+    const sc_f32x2 p01 = f01 * r2, p23 = f23 * r2;
     const sc_f32x2 t01 = p01 * m2, t23 = p23 * m2;
     const float th[4] = {t01.x, t01.y, t23.x, t23.y};
     uint32_t lo = 0xffffffffu, hi = 0;
