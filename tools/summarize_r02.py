@@ -32,9 +32,11 @@ def kernel_stats(db_path):
     return [(short(n), c, a / 1e3, mn / 1e3, mx / 1e3, t / 1e3) for n, c, a, mn, mx, t in rows]
 
 
-def counter(db_path, name):
+def counter(db_path, name, agg="avg"):
+    """per kernel: (launches, avg value) — or the largest value (calibration: the context's 16-byte warm-up launch of the
+    copy kernel must not be averaged with the 1 GiB copies)"""
     db = sqlite3.connect(db_path)
-    rows = db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name",
+    rows = db.execute("select kernel_name, count(*), %s(value) from counters_collection where counter_name = ? group by kernel_name" % agg,
                       (name,)).fetchall()
     return {short(n): (c, a) for n, c, a in rows}
 
@@ -47,8 +49,8 @@ def main():
              "`%s`." % bench.kernel_source_sha(), ""]
     result = {"kernel_source_sha": bench.kernel_source_sha()}
     # calibration of the counters on a copy of known size
-    cal_f = counter(db_of(os.path.join(src, "cal_fetch")), "FETCH_SIZE")
-    cal_w = counter(db_of(os.path.join(src, "cal_write")), "WRITE_SIZE")
+    cal_f = counter(db_of(os.path.join(src, "cal_fetch")), "FETCH_SIZE", "max")
+    cal_w = counter(db_of(os.path.join(src, "cal_write")), "WRITE_SIZE", "max")
     ck = [k for k in cal_f if "copy_kernel" in k]
     fscale = wscale = None
     if ck:
