@@ -385,19 +385,27 @@ def main():
             gather = {"what": "RCCL send/recv of every rank's output chunk into rank 0, in rank order (not in `value`)",
                       "ms": round(tg * 1e3, 3), "GB_per_s_into_rank0": round((world - 1) * 4 * n / tg / 1e9, 2)}
             del buf
+        except Exception as e:   # reported, not fatal: the headline does not depend on the gather
+            gather = {"error": str(e)[:300]}
+        try:
             # the alternative a host-side consumer (stdout) really wants: every GPU copies its own chunk to pinned host
             # memory over its own PCIe link, all at once (what `doppler --gpus N` / dpx_stream_create_multi does)
-            ho = torch.empty(2 * n, dtype=torch.int16).pin_memory()
+            ho = None
+            try:
+                ho = torch.empty(2 * n, dtype=torch.int16).pin_memory()
+            except Exception:
+                ho = torch.empty(2 * n, dtype=torch.int16)          # pageable: slower, but every rank still takes part
             barrier()
             td = time.perf_counter()
             ho.copy_(out, non_blocking=True)
             barrier()
             td = time.perf_counter() - td
-            gather["per_gpu_d2h"] = {"what": "every rank copies its chunk to pinned host memory concurrently (no gather through one GPU)",
+            gather["per_gpu_d2h"] = {"what": "every rank copies its chunk to %s host memory concurrently (no gather through one GPU)"
+                                             % ("pinned" if ho.is_pinned() else "pageable"),
                                      "ms": round(td * 1e3, 3), "GB_per_s_aggregate": round(world * 4 * n / td / 1e9, 2)}
             del ho
-        except Exception as e:   # reported, not fatal: the headline does not depend on the gather
-            gather = {"error": str(e)[:300]}
+        except Exception as e:
+            gather["per_gpu_d2h"] = {"error": str(e)[:300]}
         gather_state["done"] = True
         timer.cancel()
 

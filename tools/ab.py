@@ -60,6 +60,11 @@ def cases(which):
         for secs in (150, 262, 600):
             for comp in (0, 1):
                 c.append(("track %d s replay" % secs, lambda f, t=secs: track_segs(t, f), "i16:i16", 3, dict(walk_compute=comp)))
+    if which == "t600":
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        c.append(("const 5001 Hz", lambda f: const_segs(5001), "i16:i16", 3, {}))
+        for opts in (dict(), dict(walk_waves=8), dict(walk_waves=5)):
+            c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, opts))
     if which == "f32":
         c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
         for pair in ("f32:f32", "i16:f32", "f32:i16", "i16:i16"):
@@ -126,7 +131,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
