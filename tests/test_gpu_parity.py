@@ -705,3 +705,40 @@ def test_stream_api_ring_of_slabs(ctx, orc):
     with pytest.raises(doppler_amd.DspError):
         st.submit(16, [(1, 1.0)])                               # segments do not add up
     st.close()
+
+
+def test_stream_ring_over_several_contexts(ctx, orc):
+    """dpx_stream_create_multi: the slab ring dealt out over three contexts (all on this box's one GPU; slab k runs on
+    context k mod 3), shifts changing inside and between slabs, counter carried on the host — the same bytes as one
+    sequential oracle pass, and the same as the single-context ring."""
+    import doppler_amd
+    rate = 1024000
+    rng = np.random.default_rng(99)
+    others = [doppler_amd.Context(0), doppler_amd.Context(0)]
+    try:
+        st = doppler_amd.Stream([ctx] + others, "i16", "f32", rate, slab_bytes=1 << 18, n_slabs=2)      # 6 slabs in the ring
+        n_slabs, per = 23, (1 << 18) // 4
+        x = make_iq("i16", n_slabs * per - 1000, 71, full_scale=True)
+        plan, pos = [], 0
+        for k in range(n_slabs):
+            n = min(per, x.size // 4 - pos)
+            cut = int(rng.integers(1, n))
+            plan.append((pos, n, [(cut, float(np.float32(5001.0 + 17.5 * k))), (n - cut, float(np.float32(-3000.0 - k)))]))
+            pos += n
+        outs = []
+        for pos, n, segs in plan:
+            if st.pending() == 6:
+                outs.append(st.next())
+            buf = st.acquire()
+            buf[: n * 4] = x[pos * 4:(pos + n) * 4]
+            st.submit(n * 4, segs)
+        while st.pending():
+            outs.append(st.next())
+        got = np.concatenate(outs)
+        want, sn = orc.segments_stream(x, "i16", "f32", [sg for _, _, segs in plan for sg in segs], rate, threads=8)
+        assert st.samplenum == sn
+        assert_same_bytes(got, want, "f32", "ring over three contexts")
+        st.close()
+    finally:
+        for c in others:
+            c.close()
