@@ -404,8 +404,12 @@ int dpx_ctx_create(int device, dpx_ctx **out)
     // Load the kernels' code object now (the HIP runtime does it at the first launch, ~8 ms): a first plan or a first
     // 8 KiB block should not pay for it.  A 16-byte copy inside a scratch allocation is the cheapest launch there is.
     void *warm = nullptr;
-    if (hipMalloc(&warm, 64) == hipSuccess) {
+    if (hipMalloc(&warm, 1 << 20) == hipSuccess) {
         (void)dpx::launch_copy(warm, static_cast<char *>(warm) + 32, 16, ctx->stream);
+        (void)dpx::launch_build_lut(warm, 4, 1, 4, 0.25f, ctx->fma, ctx->stream);
+        // and the runtime's staging path for a copy from pageable memory (a plan's image: tens of KiB; 6.4 ms the first time)
+        std::vector<char> image(64 << 10, 0);
+        (void)hipMemcpyAsync(warm, image.data(), image.size(), hipMemcpyHostToDevice, ctx->stream);
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(warm);
     }

@@ -429,7 +429,14 @@ template <int IN_FMT, int OUT_FMT> struct WalkVec {
     // vector per lane per row).  Such a window is therefore shared by TWO workgroups, 128 columns each (the grid is
     // doubled at launch; the plan, which does not know the formats, is unchanged).
     static constexpr int kSplit = (S == 2 && !kTranspose) ? 2 : 1;
-    static constexpr uint32_t kCols = kWalkWindow / kSplit;              // columns a workgroup takes
+    // The opposite — TWO adjacent windows (512 columns, two vectors per lane per row, one slice of 544 correctors) per
+    // i16 -> i16 workgroup, half as many workgroups — is built in (-DDPX_WALK_MERGE=2) and measures 3-5 points slower on
+    // replays and const-mode walks alike (profiles/r02_walk.md): it is not the number of workgroups that costs.
+#ifndef DPX_WALK_MERGE
+#define DPX_WALK_MERGE 1
+#endif
+    static constexpr int kMerge = (S == 4) ? DPX_WALK_MERGE : 1;
+    static constexpr uint32_t kCols = kWalkWindow * kMerge / kSplit;     // columns a workgroup takes
     static constexpr uint32_t kEntries = kCols + kWalkPad;               // slice entries it needs
 };
 
@@ -438,9 +445,12 @@ template <int IN_FMT, int OUT_FMT> struct WalkVec {
 // every k — conflict-free ds_read_b64 whatever the row's shift (a plain array read at a lane stride of S entries is
 // 4-way conflicted: 30 % of the LDS cycles in round 1).  The plane stride makes the fills conflict-free as well
 // (planes 16 or 8 banks apart).
-template <int S> struct SlicePlanes {
-    static constexpr uint32_t kPlanes = S, kLog2 = S == 4 ? 2 : 1, kStride = 304 / S;
-    static_assert(kStride * kPlanes >= kWalkSlice + kPlanes && kWalkSlice % kPlanes == 0, "planes hold the slice");
+template <int S, uint32_t ENTRIES> struct SlicePlanes {
+    static constexpr uint32_t kPlanes = S, kLog2 = S == 4 ? 2 : 1;
+    // entries per plane + 1, rounded up to 4 (mod 8) for four planes / 8 (mod 16) for two: plane bases 8 / 16 banks apart
+    static constexpr uint32_t kNeed = ENTRIES / S + 1;
+    static constexpr uint32_t kStride = S == 4 ? ((kNeed + 3) / 8) * 8 + 4 : ((kNeed + 7) / 16) * 16 + 8;
+    static_assert(kStride >= kNeed && ENTRIES % kPlanes == 0, "planes hold the slice");
     static __device__ __forceinline__ uint32_t index(uint32_t e) { return (e & (kPlanes - 1)) * kStride + (e >> kLog2); }
 };
 
@@ -454,13 +464,13 @@ __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_
     typedef WalkVec<IN_FMT, OUT_FMT> WV;
     constexpr int NV = (int)WV::kCols / (kRowsLanes * S);         // vectors per lane per row: 1 (2 for f32 -> i16)
     constexpr uint32_t kEntries = WV::kEntries;                   // 288, or 160 for half a window
-    const uint32_t col0 = w * kWalkWindow + half * WV::kCols;     // first column of this workgroup
+    const uint32_t col0 = w * kWalkWindow + half * WV::kCols;     // first column of this workgroup (w: its first window)
     constexpr int THREADS = WAVES * 64;
     constexpr int IB = Fmt<IN_FMT>::kBytes, OB = Fmt<OUT_FMT>::kBytes;
     constexpr int QW = S * IB / 4;                                // input dwords per vector
     typedef uint32_t qvec __attribute__((ext_vector_type(QW)));
     constexpr bool XP = WalkVec<IN_FMT, OUT_FMT>::kTranspose;
-    typedef SlicePlanes<S> SP;
+    typedef SlicePlanes<S, kEntries> SP;
 
     const uint32_t r0 = ws.row0 + wave * U;
     // A wavefront past the last row of the chunk has nothing to do; unless it produces part of the slice (the first
@@ -583,6 +593,10 @@ __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_
     }
 }
 
+template <int IN_FMT, int OUT_FMT, bool FMA, int THREADS>
+__device__ __forceinline__ void leftover_block(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const LeftRange *__restrict__ left,
+                                               const uint32_t *__restrict__ lhint, const DevSeg *__restrict__ segs, uint32_t e, uint32_t tid);
+
 template <int IN_FMT, int OUT_FMT, bool FMA, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restrict__ in,
                                                             uint8_t *__restrict__ out,
@@ -598,7 +612,8 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
     constexpr int S = WalkVec<IN_FMT, OUT_FMT>::S;
     constexpr int THREADS = WAVES * 64;
     constexpr bool XP = WalkVec<IN_FMT, OUT_FMT>::kTranspose;
-    __shared__ float2 slice[SlicePlanes<S>::kPlanes * SlicePlanes<S>::kStride];
+    typedef SlicePlanes<S, WalkVec<IN_FMT, OUT_FMT>::kEntries> SPK;
+    __shared__ float2 slice[SPK::kPlanes * SPK::kStride];
     __shared__ uint32_t xpose[XP ? WAVES * (int)kWalkMaxRowsPerWave * (int)kWalkWindow : 1];   // packed i16 samples of one row per (wavefront, u)
     const uint32_t tid = threadIdx.x;
 
@@ -606,10 +621,11 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
     // matrix (replicated per group; chunks start on multiples of 8 workgroups) or a group of leftover blocks.  The
     // leftover groups (sincos per sample, VALU-bound) are spread evenly between the chunks by the planner, so that they
     // run beside memory-bound workgroups.
-    constexpr uint32_t kSplit = WalkVec<IN_FMT, OUT_FMT>::kSplit;     // workgroups per window (grid scaled at launch)
-    const uint32_t b = blockIdx.x / kSplit, half = blockIdx.x % kSplit;
+    constexpr uint32_t kSplit = WalkVec<IN_FMT, OUT_FMT>::kSplit;     // workgroups per window / windows per workgroup
+    constexpr uint32_t kMerge = WalkVec<IN_FMT, OUT_FMT>::kMerge;     // (grid scaled at launch; one of the two is 1)
+    const uint32_t b = blockIdx.x * kMerge / kSplit, half = blockIdx.x % kSplit;   // the plan's index of the first window taken
     const WalkSeg ws = wdesc[b >> kWalkHintShift];
-    const uint32_t w = b - ws.wg_base;
+    const uint32_t w = b - ws.wg_base;                            // a multiple of kMerge: chunks start on multiples of 8
     if (w >= ws.nw) return;                                       // padding
     if (ws.upw != 0) {
         // the wavefront index is uniform: telling the compiler so keeps all the row geometry in scalar registers
@@ -646,7 +662,18 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
     } else {
         // ---- leftover ranges: one block of kLeftBlock samples of ONE stretch, sincos per sample
         if (half != 0) return;                                    // a leftover block is one workgroup whatever the grid scaling
-        const uint32_t e = ws.row0 + w;                           // index of this block among all leftover blocks
+        for (uint32_t wi = w; wi < w + kMerge && wi < ws.nw; ++wi)   // (kMerge blocks, one after the other, where windows are merged)
+            leftover_block<IN_FMT, OUT_FMT, FMA, THREADS>(in, out, left, lhint, segs, ws.row0 + wi, tid);
+    }
+}
+
+// one block of kLeftBlock samples of ONE stretch, sincos per sample (lead-ins, heads, tails, stretches too short for a matrix)
+template <int IN_FMT, int OUT_FMT, bool FMA, int THREADS>
+__device__ __forceinline__ void leftover_block(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const LeftRange *__restrict__ left,
+                                               const uint32_t *__restrict__ lhint, const DevSeg *__restrict__ segs, uint32_t e, uint32_t tid)
+{
+    {
+        // e: index of this block among all leftover blocks
         uint32_t li = lhint[e >> kLeftHintShift];
         while (left[li + 1].wg_off <= e) ++li;                    // sentinel at the end
         const LeftRange lr = left[li];
@@ -897,7 +924,7 @@ static int walk_t(const void *d_in, void *d_out, const DevSeg *d_segs, const voi
     uint8_t *sink = static_cast<uint8_t *>(d_sink);
     const float2 *lut = static_cast<const float2 *>(d_lut);
     // the whole grid: row chunks and the groups of leftover blocks between them; x2 where a window is shared by two workgroups
-    const uint64_t n_wg = (uint64_t)w.n_walk_wg * WalkVec<IN_FMT, OUT_FMT>::kSplit;
+    const uint64_t n_wg = (uint64_t)w.n_walk_wg * WalkVec<IN_FMT, OUT_FMT>::kSplit / WalkVec<IN_FMT, OUT_FMT>::kMerge;
     if (n_wg == 0) return DPX_OK;
     if (n_wg > 0x7fffffffull) return DPX_ERR_ARG;
     const dim3 grid((uint32_t)n_wg);

@@ -491,7 +491,8 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
                 w.tab_off = (uint32_t)pool;
                 const uint32_t P = s.period;
                 const uint32_t n_first = (uint32_t)(((uint64_t)w.phase + (uint64_t)P * kWalkPad - kWalkPad) % P) + 1u;
-                const uint32_t n_entries = w.nw * kWalkWindow + kWalkPad;     // every window reads a whole 288-entry slice
+                // every window reads a whole slice; one window more, because an i16 -> i16 workgroup takes two windows at once
+                const uint32_t n_entries = (w.nw + 1) * kWalkWindow + kWalkPad;
                 plan.tables.push_back({pool, P, n_first, n_entries, s.ratio});
                 pool += ((uint64_t)n_entries + 3) & ~3ull;
             }

@@ -60,6 +60,14 @@ def cases(which):
         for secs in (150, 262, 600):
             for comp in (0, 1):
                 c.append(("track %d s replay" % secs, lambda f, t=secs: track_segs(t, f), "i16:i16", 3, dict(walk_compute=comp)))
+    if which == "merge":
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for shift in (5001, 12345, 777):
+            c.append(("const %d Hz" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 3, {}))
+        for opts in (dict(), dict(walk_waves=8), dict(walk_waves=5), dict(walk_waves=4), dict(walk_compute=0)):
+            c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, opts))
+        for rows in (3, 5, 9, 13):
+            c.append(("synth %d rows of P=65536" % rows, lambda f, r=rows: synth_segs(r), "i16:i16", 3, dict()))
     if which == "t600":
         c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
         c.append(("const 5001 Hz", lambda f: const_segs(5001), "i16:i16", 3, {}))
@@ -131,7 +139,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
