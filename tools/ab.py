@@ -60,6 +60,12 @@ def cases(which):
         for secs in (150, 262, 600):
             for comp in (0, 1):
                 c.append(("track %d s replay" % secs, lambda f, t=secs: track_segs(t, f), "i16:i16", 3, dict(walk_compute=comp)))
+    if which == "rowsopt":
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for shift, rate in ((100, RATE), (9876.543, RATE), (815000, 2400000), (5000, RATE), (2500, RATE), (200, RATE), (50, RATE), (25, RATE), (-15000, 256000)):
+            for pair in ("i16:i16", "f32:f32"):
+                for opts in (dict(), dict(rows_r=4)):
+                    c.append(("const %g Hz @%d" % (shift, rate), lambda f, s=shift: const_segs(s), pair, 6, dict(opts, _rate=rate)))
     if which == "merge":
         c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
         for shift in (5001, 12345, 777):
@@ -139,7 +145,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
