@@ -451,7 +451,7 @@ int dpx_set_options(dpx_ctx *ctx, const dpx_options *opt)
     if (opt) {
         if (opt->rows_r != 0 && opt->rows_r != 2 && opt->rows_r != 4 && opt->rows_r != 8) return fail(DPX_ERR_ARG, "rows_r must be 2, 4 or 8");
         const uint32_t ww = opt->walk_waves;
-        if (ww != 0 && ww != 4 && ww != 5 && ww != 6 && ww != 8) return fail(DPX_ERR_ARG, "walk_waves must be 4, 5, 6 or 8");
+        if (ww != 0 && (ww < 2 || ww > 8 || ww == 7)) return fail(DPX_ERR_ARG, "walk_waves must be 2, 3, 4, 5, 6 or 8");
         if (opt->walk_rows > 4) return fail(DPX_ERR_ARG, "walk_rows must be 1..4");
     }
     ctx->tuning = tuning_of(opt);

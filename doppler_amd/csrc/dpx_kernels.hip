@@ -22,6 +22,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef DPX_WALK_ACTIVE_ONLY
+#define DPX_WALK_ACTIVE_ONLY 1
+#endif
+
 namespace dpx {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -480,8 +484,17 @@ __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_
     // with row counts that leave 1..WAVES-1 wavefronts without rows.
     // Measured alternative (profiles/r02_walk.md): only the wavefronts WITH rows evaluate the slice, so that the others
     // leave at once — slower everywhere (the serial evaluations delay the surviving wavefronts past their loads).
+#if DPX_WALK_ACTIVE_ONLY
+    // Evaluated slices: the wavefronts WITH rows share the evaluation; one without rows leaves at once instead of
+    // holding its slot until the barrier (a 9-row second fills 5 of 8 wavefronts: every one-second matrix has such
+    // chunks).  The shared loop is unrolled with a compile-time trip count — a loop with a run-time stride makes the
+    // compiler wait for the sample loads at its entry.
+    const uint32_t n_act = (ws.row_end - ws.row0 + U - 1) / U;      // wavefronts with rows: 1..WAVES (uniform)
+    if (r0 >= ws.row_end && (compute || wave * kRowsLanes >= kEntries / 2)) return;
+#else
     const uint32_t slice_threads = compute ? kEntries : kEntries / 2;
     if (r0 >= ws.row_end && wave * kRowsLanes >= slice_threads) return;
+#endif
     qvec qin[U][NV];
     uint32_t off[U];                                          // slice entry of the row's column 0 (uniform per wavefront)
     uint8_t *op[U][NV];
@@ -514,19 +527,31 @@ __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_
         const uint32_t P = ws.period;
         // counter of column c: ((phase + c) mod P) + 1, c = 256 w + j - kWalkPad >= -kWalkPad
         const uint32_t ub = ws.phase + col0;                  // < period + L + 255 < 2^24
+#if DPX_WALK_ACTIVE_ONLY
+        const uint32_t stride = n_act * kRowsLanes;
+        constexpr int kMaxIt = ((int)kEntries + kRowsLanes - 1) / kRowsLanes;      // one wavefront alone: 5 (3 for half a window)
+#pragma unroll
+        for (int it = 0; it < kMaxIt; ++it) {
+            if ((uint32_t)it * stride >= kEntries) break;     // uniform
+            const uint32_t j = tid + (uint32_t)it * stride;
+            if (j < kEntries) {
+#else
         for (uint32_t j = tid; j < kEntries; j += THREADS) {
-            uint32_t t;
-            if (ws.L == P) {                                  // P >= kWalkMinL > kWalkPad: at most two wraps
-                t = ub + j + P - kWalkPad;
-                t = t >= 2u * P ? t - 2u * P : t;
-                t = t >= P ? t - P : t;
-                t = t >= P ? t - P : t;
-            } else {
-                t = (uint32_t)(((uint64_t)ub + j + (uint64_t)P * kWalkPad - kWalkPad) % P);
+            {
+#endif
+                uint32_t t;
+                if (ws.L == P) {                              // P >= kWalkMinL > kWalkPad: at most two wraps
+                    t = ub + j + P - kWalkPad;
+                    t = t >= 2u * P ? t - 2u * P : t;
+                    t = t >= P ? t - P : t;
+                    t = t >= P ? t - P : t;
+                } else {
+                    t = (uint32_t)(((uint64_t)ub + j + (uint64_t)P * kWalkPad - kWalkPad) % P);
+                }
+                float c, sn;
+                corrector<FMA>(ws.ratio, t + 1u, c, sn);
+                slice[SP::index(j)] = make_float2(c, sn);
             }
-            float c, sn;
-            corrector<FMA>(ws.ratio, t + 1u, c, sn);
-            slice[SP::index(j)] = make_float2(c, sn);
         }
     } else {
 #pragma unroll
@@ -685,19 +710,21 @@ __device__ __forceinline__ void leftover_block(const uint8_t *__restrict__ in, u
         uint32_t base;   // periodic: phase of g0 in [0, P); linear: the counter itself
         if (P != 0) base = (uint32_t)(((uint64_t)(sg.n_start - 1u) + j0) % P);
         else        base = sg.n_start + (uint32_t)j0;
-        static_assert(kLeftBlock == 4 * 256 && THREADS >= 256, "a leftover block is four samples for each of 256 threads");
-        if (tid >= 256) return;
+        static_assert(kLeftBlock == 4 * 256, "a leftover block is four samples for each of 256 thread slots");
+        // 256 thread slots q; a workgroup of fewer threads takes them in turns (compile-time trip count)
+#pragma unroll
+        for (uint32_t q = tid; q < 256u; q += THREADS) {
         if (o0 + kLeftBlock <= lr.len && (P == 0 || P >= 4)) {
             // a whole block: four CONSECUTIVE samples per thread, moved as 16-byte vectors (a block starts wherever its
             // range does, so the vectors are only sample-aligned: the hardware takes unaligned global accesses)
             constexpr int IB = Fmt<IN_FMT>::kBytes, OB = Fmt<OUT_FMT>::kBytes;
             typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-            const uint64_t g = g0 + tid * 4u;
+            const uint64_t g = g0 + q * 4u;
             u32x4_u qv[Fmt<IN_FMT>::kVecs];
 #pragma unroll
             for (int i = 0; i < Fmt<IN_FMT>::kVecs; ++i) qv[i] = *(reinterpret_cast<const u32x4_u *>(in + g * IB) + i);
             f32x2 cs[4];
-            uint32_t t = base + tid * 4u;
+            uint32_t t = base + q * 4u;
             if ((P == 0 || base + kLeftBlock <= P) && base < (1u << 24) - kLeftBlock - 1u) {
                 // no wrap inside the block and every counter below 2^24 (uniform): the usual case, lead-ins above all
                 corrector4_consecutive<FMA>(sg.ratio, P == 0 ? t : t + 1u, cs);
@@ -734,15 +761,15 @@ __device__ __forceinline__ void leftover_block(const uint8_t *__restrict__ in, u
                 *(reinterpret_cast<u32x4_u *>(out + g * OB) + i) = o;
             }
         } else {
-            // the last block of a range (or a period below 4): sample by sample, o = tid + k * 256
-            if (o0 + tid >= lr.len) return;
+            // the last block of a range (or a period below 4): sample by sample, o = q + k * 256
+            if (o0 + q >= lr.len) continue;
             uint32_t n[4];
             bool have[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t o = tid + (uint32_t)k * 256u;
+                const uint32_t o = q + (uint32_t)k * 256u;
                 have[k] = o0 + o < lr.len;
-                const uint32_t oo = have[k] ? o : tid;
+                const uint32_t oo = have[k] ? o : q;
                 if (P == 0) {
                     n[k] = base + oo;
                 } else if (P >= kLeftBlock) {                         // base < P and o < kLeftBlock: at most one wrap
@@ -757,12 +784,13 @@ __device__ __forceinline__ void leftover_block(const uint8_t *__restrict__ in, u
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (!have[k]) continue;
-                const uint32_t o = tid + (uint32_t)k * 256u;
+                const uint32_t o = q + (uint32_t)k * 256u;
                 float a, bq, re, im;
                 load_one<IN_FMT>(in, g0 + o, a, bq);
                 mix(a, bq, cs[k].x, cs[k].y, re, im);
                 store_one<OUT_FMT>(out, g0 + o, re, im);
             }
+        }
         }
     }
 }
@@ -934,7 +962,7 @@ static int walk_t(const void *d_in, void *d_out, const DevSeg *d_segs, const voi
         else     walk_kernel<IN_FMT, OUT_FMT, false, WW><<<grid, WW * 64, 0, st>>>(in, out, lut, d_wdesc, w.n_left_wg, sink, d_left, d_lhint, d_segs); \
         return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                                                 \
     }
-    DPX_WALK_CASE(5) DPX_WALK_CASE(4) DPX_WALK_CASE(6) DPX_WALK_CASE(8)
+    DPX_WALK_CASE(5) DPX_WALK_CASE(4) DPX_WALK_CASE(6) DPX_WALK_CASE(8) DPX_WALK_CASE(3) DPX_WALK_CASE(2)
 #undef DPX_WALK_CASE
     return DPX_ERR_ARG;
 }

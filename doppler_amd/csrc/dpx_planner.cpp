@@ -379,6 +379,13 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         use_walk = in_matrices > 0 && in_matrices >= plan.n_samples / 2 && n_wg < 0x40000000ull;
     }
 
+    // Workgroup shape of the walk launch: 4 wavefronts x 2 rows for track-shaped plans (a second of stream is 5-40 rows:
+    // small workgroups waste fewer wavefront slots on the partly filled chunks every such matrix ends with), 5 x 2 for
+    // the long matrices of const-mode plans (measured, profiles/r02_walk.md: replay 74.8 / 72.4 % with 4 / 5 wavefronts,
+    // const 5001 Hz 78.8 / 80.0 %).
+    PlanTuning tnw = tn;
+    if (!tnw.walk_waves) tnw.walk_waves = use_walk ? kWalkWavesTrack : kWalkWaves;
+
     // Const-mode plans: a stretch whose period does not allow rows of whole 4 KiB pages (odd periods: the common case
     // for an arbitrary integer --shift) runs 4-23 % faster as a walk-kernel matrix than as a rows launch with
     // L = 32 P (measured, profiles/r01_secondary_workloads.md), and a stretch too short for a rows launch is better off
@@ -530,9 +537,9 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         // The leftover workgroups (sincos per sample: VALU-bound) are dealt out in groups of 8 between the chunks, evenly
         // over the grid, so that their arithmetic runs beside memory-bound matrix workgroups on every CU instead of in a
         // block of its own (all at the front: 5-8 % of the 600-second replay for 1 % of its samples; at the end: worse).
-        const uint32_t waves = walk_shape(tn).waves, max_upw = walk_shape(tn).rows_per_wave;
+        const uint32_t waves = walk_shape(tnw).waves, max_upw = walk_shape(tnw).rows_per_wave;
         uint64_t m_groups = 0;
-        for (const WalkSeg &m : mats) m_groups += (uint64_t)((m.nw + 7) / 8) * walk_chunks(m, tn);
+        for (const WalkSeg &m : mats) m_groups += (uint64_t)((m.nw + 7) / 8) * walk_chunks(m, tnw);
         const uint64_t l_groups = (left_wg + 7) / 8;
         uint64_t wg = 0, m_done = 0, l_done = 0;
         auto deal_leftovers = [&](uint64_t upto) {          // leftover groups [l_done, upto) go here
@@ -548,7 +555,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
             }
         };
         for (size_t mi = 0; mi < mats.size(); ++mi) {
-            const uint32_t k = walk_chunks(mats[mi], tn);
+            const uint32_t k = walk_chunks(mats[mi], tnw);
             for (uint32_t c = 0; c < k; ++c) {
                 WalkSeg w = mats[mi];
                 const uint32_t base = w.rows / k, rem = w.rows % k;
@@ -570,8 +577,8 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         ln.walk.n_walk_wg = (uint32_t)wg;            // the whole grid, leftover groups included
         ln.walk.n_left_wg = (uint32_t)left_wg;       // leftover blocks among them
         ln.walk.n_segs = (uint32_t)ns;
-        ln.walk.waves = walk_shape(tn).waves;
-        ln.walk.rows_per_wave = walk_shape(tn).rows_per_wave;
+        ln.walk.waves = walk_shape(tnw).waves;
+        ln.walk.rows_per_wave = walk_shape(tnw).rows_per_wave;
         ln.walk.compute_slice = 0;
         for (const WalkSeg &m : mats) if (m.tab_off == kWalkNoTable) ln.walk.compute_slice = 1;
         plan.launches.push_back(ln);

@@ -121,7 +121,8 @@ constexpr uint32_t kWalkMinL = 8192;       // shorter periods use a multiple as 
 constexpr int kWalkHintShift = 3;          // one WalkSeg index per 8 workgroups: exact, every chunk is padded to a multiple of 8
 constexpr int kLeftHintShift = 4;          // one LeftRange hint per 16 leftover workgroups
 constexpr uint32_t kLeftBlock = 1024;      // samples per leftover workgroup
-constexpr uint32_t kWalkWaves = 8;         // wavefronts per workgroup ...
+constexpr uint32_t kWalkWaves = 5;         // wavefronts per workgroup (const-mode walks; track-shaped plans: kWalkWavesTrack) ...
+constexpr uint32_t kWalkWavesTrack = 4;
 constexpr uint32_t kWalkRowsPerWave = 2;   // ... and the most rows a wavefront takes by default (measured best; the kernel handles 1..4 per chunk)
 constexpr uint32_t kWalkMaxRowsPerWave = 4;
 constexpr uint32_t kWalkSlice = kWalkWindow + kWalkPad;   // table entries a window needs: 288

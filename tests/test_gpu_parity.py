@@ -363,7 +363,7 @@ def test_walk_kernel_plans_vs_oracle(ctx, orc, intype, outtype):
 
 
 @pytest.mark.parametrize("compute", [0, 1])
-@pytest.mark.parametrize("waves,max_rows", [(4, 4), (5, 4), (6, 4), (8, 4), (5, 1), (5, 2), (5, 3), (8, 2)])
+@pytest.mark.parametrize("waves,max_rows", [(4, 4), (5, 4), (6, 4), (8, 4), (5, 1), (5, 2), (5, 3), (8, 2), (2, 2), (3, 2), (4, 2)])
 def test_walk_kernel_workgroup_shapes_and_on_the_fly_slices(ctx, orc, waves, max_rows, compute):
     """Every workgroup shape of the walk kernel, with plan-time tables (compute=0) and with the workgroups evaluating
     their corrector slices themselves (compute=1), with chunks of 1..4 rows per wavefront, on matrices whose row counts

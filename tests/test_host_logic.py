@@ -129,7 +129,7 @@ def test_walk_kernel_plans(orc):
             assert np.array_equal(c, want), (segs[:3], variant, np.flatnonzero(c != want)[:5])
         # the measurement knobs (dpx_options) change the launch shapes, never the counters
         for opts in (dict(walk_compute=1), dict(walk_compute=0), dict(walk_table_rows=3), dict(walk_waves=4), dict(walk_waves=8, walk_compute=1), dict(walk_waves=6, walk_tilemin=1000),
-                     dict(rows_r=4, rows_mult=3), dict(walk_rows=1), dict(walk_rows=2, walk_waves=4), dict(walk_rows=3, walk_compute=1)):
+                     dict(rows_r=4, rows_mult=3), dict(walk_rows=1), dict(walk_rows=2, walk_waves=4), dict(walk_waves=2), dict(walk_waves=3, walk_compute=0), dict(walk_rows=3, walk_compute=1)):
             c, w = doppler_amd.plan_simulate(segs, rate, sn0, 128, 2, 3, options=opts)
             assert (w == 1).all() and np.array_equal(c, want), (i, opts)
             if "walk_compute" in opts and i < 3:    # tables for every matrix / for none

@@ -66,6 +66,16 @@ def cases(which):
             for pair in ("i16:i16", "f32:f32"):
                 for opts in (dict(), dict(rows_r=4)):
                     c.append(("const %g Hz @%d" % (shift, rate), lambda f, s=shift: const_segs(s), pair, 6, dict(opts, _rate=rate)))
+    if which == "waves":
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for waves in (2, 3, 4, 5, 6, 8):
+            o = dict(walk_waves=waves)
+            c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, o))
+            c.append(("track 300 s replay", lambda f: track_segs(300, f), "f32:i16", 3, o))
+            c.append(("track 300 s replay", lambda f: track_segs(300, f), "f32:f32", 3, o))
+            c.append(("const 5001 Hz", lambda f: const_segs(5001), "i16:i16", 3, o))
+            c.append(("const 12345 Hz", lambda f: const_segs(12345), "i16:i16", 3, o))
+            c.append(("const 5001 Hz", lambda f: const_segs(5001), "f32:f32", 3, o))
     if which == "merge":
         c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
         for shift in (5001, 12345, 777):
@@ -145,7 +155,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
