@@ -148,11 +148,15 @@ __device__ __forceinline__ double reduce_large(uint32_t xi, uint32_t &quad, uint
     const uint64_t res2 = (uint64_t)m * a8;
     res0 = (res2 >> 32) | (res0 << 32);
     res0 += res1;
-    const uint64_t n = (res0 + (1ULL << 61)) >> 62;
-    res0 -= n << 62;
-    quad = (uint32_t)n;
-    sidx = (uint32_t)n + (xi >> 31);
-    return (double)(int64_t)res0 * PI63;
+    // n = round(res0 / 2^62); res0 - n*2^62 only changes the high word, and the signed 64-bit remainder converts
+    // to double with one rounding either way: hi*2^32 is exact, lo is exact, the fused add rounds their sum once.
+    const uint32_t hi = (uint32_t)(res0 >> 32), lo = (uint32_t)res0;
+    const uint32_t t = hi + 0x20000000u;
+    const uint32_t n = t >> 30;
+    const int32_t rem_hi = (int32_t)((t & 0x3fffffffu) - 0x20000000u);
+    quad = n;
+    sidx = n + (xi >> 31);
+    return __builtin_fma((double)rem_hi, 4294967296.0, (double)lo) * PI63;
 }
 
 template <bool FMA>

@@ -66,6 +66,12 @@ def cases(which):
             for pair in ("i16:i16", "f32:f32"):
                 for opts in (dict(), dict(rows_r=4)):
                     c.append(("const %g Hz @%d" % (shift, rate), lambda f, s=shift: const_segs(s), pair, 6, dict(opts, _rate=rate)))
+    if which == "bigp":
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for shift, rate in ((3, RATE), (1, RATE), (10, RATE), (7, 2400000), (25, RATE), (100, RATE)):
+            for pair in ("i16:i16", "f32:f32", "f32:i16"):
+                for variant in (6, 5):
+                    c.append(("const %g Hz @%d" % (shift, rate), lambda f, s=shift: const_segs(s), pair, variant, dict(_rate=rate)))
     if which == "waves":
         c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
         for waves in (2, 3, 4, 5, 6, 8):
@@ -155,7 +161,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
