@@ -50,7 +50,8 @@ struct dpx_ctx {
     int n_cu = 0;
     bool fma = true;          // libm variant whose sincosf the kernels reproduce
     int block = 128;          // tile kernel: lanes per workgroup (128 or 256)
-    int vecs = 2;             // tile kernel: 4-sample groups per lane (1 or 2); 128 x 2 measured best
+    int vecs = 2;             // tile kernel: 4-sample groups per lane (1 or 2)
+    bool geom_auto = true;    // until dpx_set_tuning names a geometry: chosen per launch (run_plan)
     int variant = 0;
     int choice = dpx::kChooseAuto;   // which kernels finalize() may use (dpx_set_tuning)
     dpx::PlanTuning tuning;          // kernel-shape knobs (dpx_set_options)
@@ -116,6 +117,7 @@ dpx::LaunchGeom geometry(const dpx_ctx *ctx)
     dpx::LaunchGeom g;
     g.block = ctx->block;
     g.vecs = ctx->vecs;
+    g.autosel = ctx->geom_auto ? 1 : 0;
     return g;
 }
 
@@ -217,8 +219,17 @@ int materialize(dpx_ctx *ctx, const dpx::PlanResult &plan, DevPlan &dev, bool fm
 
 // every launch of a finalized plan, asynchronously on `st`
 int run_plan(const dpx::PlanResult &plan, const DevPlan &dev, const void *d_in, int in_fmt, void *d_out,
-             int out_fmt, bool fma, const dpx::LaunchGeom &g, void *st)
+             int out_fmt, bool fma, const dpx::LaunchGeom &g_in, void *st)
 {
+    // Tile-kernel geometry when the caller named none: 256 lanes x one vector, except for i16 output evaluated sample by
+    // sample (no tile tables), where 128 lanes x two vectors measures 2 points better (profiles/r02_walk.md, `--set geom`:
+    // i16->f32 sincos per sample 52.8 -> 62.8 %, tile tables 62-69 -> 66-71 %).  Both are 1024-sample tiles: the plan fits either.
+    dpx::LaunchGeom g = g_in;
+    if (g.autosel && g.tile() == 1024u) {
+        const bool wide = out_fmt == DPX_FMT_F32 || plan.tile_tables;
+        g.block = wide ? 256 : 128;
+        g.vecs = wide ? 1 : 2;
+    }
     for (const dpx::Launch &ln : plan.launches) {
         int rc;
         if (ln.kind == 0)
@@ -440,6 +451,7 @@ int dpx_set_tuning(dpx_ctx *ctx, int block, int vecs, int variant)
     if (variant < 0 || variant > 6) return fail(DPX_ERR_ARG, "variant out of range");
     if (block) ctx->block = block;
     if (vecs) ctx->vecs = vecs;
+    if (block || vecs) ctx->geom_auto = false;
     ctx->choice = choice_of(variant);
     ctx->variant = variant >= 3 ? 0 : variant;
     return DPX_OK;

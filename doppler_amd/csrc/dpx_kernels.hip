@@ -367,6 +367,15 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
         // tile takes the path with one addition per counter
         const bool wraps = P != 0 && base + TILE > P;
         const bool small = base < (1u << 24) - TILE - 1u;                 // fl32(n0 + k) = fl32(n0) + k for the whole tile
+        // sincosf's argument path for the whole tile, from the stretch's three counters (scalar comparisons)
+        int path = kPathAny;
+        if (!wraps) {
+            const uint32_t n_lo = P == 0 ? base : base + 1u, n_hi = n_lo + (TILE - 1u);
+            if (n_hi >= n_lo) {
+                if (n_lo >= sg.n_plain && n_hi < sg.n_large) path = kPathPlain;
+                else if (n_lo >= sg.n_large && n_hi < sg.n_huge) path = kPathLarge;
+            }
+        }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             uint32_t t = base + (uint32_t)(v * BLOCK + tid) * SPL;     // periodic: < P + TILE
@@ -374,10 +383,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
             if (!wraps) {
                 const uint32_t n0 = P == 0 ? t : t + 1u;                // u32 arithmetic wraps like the reference's `+= 1`
                 if (small) {                                             // every counter of the tile below 2^24 (uniform)
-                    corrector4_consecutive<FMA>(sg.ratio, n0, cs);
+                    corrector4_consecutive<FMA>(sg.ratio, n0, cs, path);
                 } else {
                     const uint32_t n[SPL] = {n0, n0 + 1u, n0 + 2u, n0 + 3u};
-                    corrector4<FMA>(sg.ratio, n, cs);
+                    corrector4<FMA>(sg.ratio, n, cs, path);
                 }
             } else {
                 uint32_t n[SPL];

@@ -138,10 +138,43 @@ static uint32_t lut_len_for(uint32_t period, uint64_t count, int variant)
     return count >= 2ull * period ? period : 0;    // a table pays once it is reused
 }
 
+// bits of |theta(n)| as the kernels compute it (dpx_sincos.h, corrector): two separately rounded f32 products
+static uint32_t theta_abs_bits(float ratio, uint32_t n)
+{
+    const float p = ratio * (float)n;
+    const float theta = -6.28318530717958647692f * p;
+    uint32_t b;
+    memcpy(&b, &theta, sizeof b);
+    return b & 0x7fffffffu;
+}
+
+// first counter whose |theta| bits are >= bound (0xffffffff: none below 2^32 - 1); |theta| is monotone in n
+static uint32_t first_counter_reaching(float ratio, uint32_t bound)
+{
+    if (theta_abs_bits(ratio, 0xfffffffeu) < bound) return 0xffffffffu;
+    uint32_t lo = 0, hi = 0xfffffffeu;                     // invariant: bits(hi) >= bound
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (theta_abs_bits(ratio, mid) >= bound) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
 static void emit(PlanResult &plan, uint64_t first, uint64_t count, float ratio, uint32_t n_start,
                  uint32_t period, uint32_t lut_len)
 {
     DevSeg s;
+    if (!plan.segs.empty() && memcmp(&plan.segs.back().ratio, &ratio, sizeof ratio) == 0) {
+        s.n_plain = plan.segs.back().n_plain;
+        s.n_large = plan.segs.back().n_large;
+        s.n_huge = plan.segs.back().n_huge;
+    } else {
+        s.n_plain = first_counter_reaching(ratio, 0x39800000u);     // 2^-12
+        s.n_large = first_counter_reaching(ratio, 0x42f00000u);     // 120
+        s.n_huge = first_counter_reaching(ratio, 0x50000000u);      // 2^33
+    }
+    s.pad = 0;
     s.first = first;
     s.count = count;
     s.ratio = ratio;
@@ -342,6 +375,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
     const size_t ns = plan.segs.size();
     uint64_t pool = 0;
     for (DevSeg &s : plan.segs) s.flags = 0;
+    plan.tile_tables = false;
 
     // ---- which kernel serves the tabulated stretches.
     // rows kernel: one launch per stretch, the fastest shape for a long stretch (const mode);
@@ -642,6 +676,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         if (!needs_tile_table) continue;
         const uint32_t P = s.period;
         s.flags |= kSegTileTable;
+        plan.tile_tables = true;
         s.c0 = (uint32_t)(((uint64_t)((s.n_start - 1u) % P) + P - (s.first % P)) % P);
         s.tmod = tile % P;
         if (prev && prev->period == P && memcmp(&prev->ratio, &s.ratio, sizeof(float)) == 0) {

@@ -68,6 +68,7 @@ struct PlanResult {
     // filled by finalize():
     uint64_t lut_entries = 0;        // size of the corrector-table pool, in (cos, sin) entries
     uint32_t tile = 0;               // tile-kernel samples per workgroup the tables were laid out for
+    bool tile_tables = false;        // some stretch is served from a tile-kernel table
     std::vector<uint32_t> hint;      // stretch index per 2^kHintShift samples
     std::vector<TableBuild> tables;
     std::vector<Launch> launches;

@@ -339,42 +339,51 @@ __device__ __forceinline__ void corrector(float ratio, uint32_t n, float &c, flo
 // decides for all four whether the wavefront may take the fast path of sincosf_glibc, and the four polynomial chains
 // are independent instruction streams for the scheduler.  cs[k] = (cos, sin) for counter n[k].
 typedef float sc_f32x2 __attribute__((ext_vector_type(2)));
-template <bool FMA>
-__device__ __forceinline__ void corrector4_f(float ratio, sc_f32x2 f01, sc_f32x2 f23, sc_f32x2 cs[4]);
+// path: what the caller knows about all the counters of the WAVEFRONT (a wavefront-uniform value; DevSeg's n_plain /
+// n_large / n_huge give it for free): kPathPlain — every |theta| in [2^-12, 120); kPathLarge — every |theta| in
+// [120, 2^33); kPathAny — nothing known, the function looks and votes.
+constexpr int kPathAny = 0, kPathPlain = 1, kPathLarge = 2;
 
 template <bool FMA>
-__device__ __forceinline__ void corrector4(float ratio, const uint32_t n[4], sc_f32x2 cs[4])
+__device__ __forceinline__ void corrector4_f(float ratio, sc_f32x2 f01, sc_f32x2 f23, sc_f32x2 cs[4], int path = kPathAny);
+
+template <bool FMA>
+__device__ __forceinline__ void corrector4(float ratio, const uint32_t n[4], sc_f32x2 cs[4], int path = kPathAny)
 {
-    corrector4_f<FMA>(ratio, sc_f32x2{(float)n[0], (float)n[1]}, sc_f32x2{(float)n[2], (float)n[3]}, cs);
+    corrector4_f<FMA>(ratio, sc_f32x2{(float)n[0], (float)n[1]}, sc_f32x2{(float)n[2], (float)n[3]}, cs, path);
 }
 
 // Four CONSECUTIVE counters n0 .. n0 + 3, all below 2^24 (the caller's uniform test): fl32(n0 + k) = fl32(n0) + k exactly,
 // so one conversion and two packed additions replace four conversions and three integer additions.
 template <bool FMA>
-__device__ __forceinline__ void corrector4_consecutive(float ratio, uint32_t n0, sc_f32x2 cs[4])
+__device__ __forceinline__ void corrector4_consecutive(float ratio, uint32_t n0, sc_f32x2 cs[4], int path = kPathAny)
 {
     const float f0 = (float)n0;
-    corrector4_f<FMA>(ratio, sc_f32x2{f0, f0} + sc_f32x2{0.0f, 1.0f}, sc_f32x2{f0, f0} + sc_f32x2{2.0f, 3.0f}, cs);
+    corrector4_f<FMA>(ratio, sc_f32x2{f0, f0} + sc_f32x2{0.0f, 1.0f}, sc_f32x2{f0, f0} + sc_f32x2{2.0f, 3.0f}, cs, path);
 }
 
 // fl32 of the four counters given: the two f32 products of theta, then the path decision
 template <bool FMA>
-__device__ __forceinline__ void corrector4_f(float ratio, sc_f32x2 f01, sc_f32x2 f23, sc_f32x2 cs[4])
+__device__ __forceinline__ void corrector4_f(float ratio, sc_f32x2 f01, sc_f32x2 f23, sc_f32x2 cs[4], int path)
 {
     const sc_f32x2 r2 = {ratio, ratio}, m2 = {-6.28318530717958647692f, -6.28318530717958647692f};
     const sc_f32x2 p01 = f01 * r2, p23 = f23 * r2;
     const sc_f32x2 t01 = p01 * m2, t23 = p23 * m2;
     const float th[4] = {t01.x, t01.y, t23.x, t23.y};
-    uint32_t lo = 0xffffffffu, hi = 0;
+    bool all_plain = path == kPathPlain, all_large = path == kPathLarge;
+    if (path == kPathAny) {
+        uint32_t lo = 0xffffffffu, hi = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t a = __float_as_uint(th[k]) & 0x7fffffffu;
-        lo = a < lo ? a : lo;
-        hi = a > hi ? a : hi;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t a = __float_as_uint(th[k]) & 0x7fffffffu;
+            lo = a < lo ? a : lo;
+            hi = a > hi ? a : hi;
+        }
+        // every |theta| in [2^-12, 120)  (nan / inf have the largest magnitudes: they fail the upper bound)
+        all_plain = __builtin_amdgcn_ballot_w64(!(lo >= 0x39800000u && hi < 0x42f00000u)) == 0;
+        all_large = !all_plain && __builtin_amdgcn_ballot_w64(!(lo >= 0x42f00000u && hi < 0x50000000u)) == 0;
     }
-    // every |theta| in [2^-12, 120)  (nan / inf have the largest magnitudes: they fail the upper bound)
-    const bool plain = lo >= 0x39800000u && hi < 0x42f00000u;
-    if (__builtin_amdgcn_ballot_w64(!plain) == 0) {
+    if (all_plain) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             uint32_t q;
@@ -383,7 +392,7 @@ __device__ __forceinline__ void corrector4_f(float ratio, sc_f32x2 f01, sc_f32x2
             sincos_poly<FMA>(xr, q, q, sn, c);
             cs[k] = sc_f32x2{c, sn};
         }
-    } else if (__builtin_amdgcn_ballot_w64(!(lo >= 0x42f00000u && hi < 0x50000000u)) == 0) {
+    } else if (all_large) {
         // every |theta| in [120, 2^33)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

@@ -27,8 +27,14 @@ struct DevSeg {
     uint32_t c0;        // (n_start - 1 - first) mod period: phase of global sample 0
     uint32_t tmod;      // tile mod period
     uint32_t flags;
+    // |theta(n)| never decreases with the counter n (every rounding in fl32(-2 pi * fl32(ratio * fl32(n))) is monotone), so
+    // the range of sincosf's argument paths is three counters, found on the host by bisection with the same f32 products:
+    // the first n whose |theta| bits reach 2^-12 / 120 / 2^33 (0xffffffff: none).  A tile whose counters lie inside
+    // [n_plain, n_large) or [n_large, n_huge) knows its path from two scalar comparisons (dpx_sincos.h, corrector4_f).
+    uint32_t n_plain, n_large, n_huge;
+    uint32_t pad;
 };
-static_assert(sizeof(DevSeg) == 48, "DevSeg is read with scalar loads");
+static_assert(sizeof(DevSeg) == 64, "DevSeg is read with scalar loads");
 
 constexpr uint32_t kSegRows = 2u;        // (most of) this stretch is served by a rows-kernel launch
 constexpr uint32_t kSegTileTable = 4u;   // lut_off / c0 / tmod describe a tile-kernel table
@@ -52,6 +58,7 @@ constexpr int kRowsLanes = 64;              // rows kernel: one wavefront per wo
 struct LaunchGeom {
     int block;    // 128 or 256 lanes per workgroup
     int vecs;     // 4-sample groups per lane: 1 or 2
+    int autosel = 0;   // the caller set neither: 128 x 2 or 256 x 1 (the same 1024-sample tile) is chosen per launch
     uint32_t tile() const { return (uint32_t)block * kSamplesPerLane * (uint32_t)vecs; }
 };
 

@@ -153,6 +153,11 @@ def cases(which):
             for pair in ("i16:i16", "f32:f32"):
                 for geom in ((128, 2), (256, 1)):
                     c.append(("const %d Hz, sincos per sample" % shift, lambda f, s=shift: const_segs(s), pair, 1, dict(_geom=geom)))
+    if which == "geom":          # tile-kernel geometry per format pair: sincos per sample and tile tables
+        for pair in ("i16:i16", "f32:f32", "f32:i16", "i16:f32"):
+            for geom in ((128, 2), (256, 1), (128, 1), (256, 2)):
+                c.append(("const 5001 Hz, sincos per sample", lambda f: const_segs(5001), pair, 1, dict(_geom=geom)))
+                c.append(("const 5001 Hz, tile tables", lambda f: const_segs(5001), pair, 4, dict(_geom=geom)))
     return c
 
 
@@ -161,7 +166,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
