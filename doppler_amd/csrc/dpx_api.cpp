@@ -446,9 +446,15 @@ void dpx_ctx_destroy(dpx_ctx *ctx)
 int dpx_set_tuning(dpx_ctx *ctx, int block, int vecs, int variant)
 {
     if (!ctx) return fail(DPX_ERR_ARG, "ctx is null");
+    if (variant < 0 || variant > 6) return fail(DPX_ERR_ARG, "variant out of range");
+    if (block == -1 && vecs == -1) {               // back to the per-launch choice
+        ctx->block = 128;
+        ctx->vecs = 2;
+        ctx->geom_auto = true;
+        block = vecs = 0;
+    }
     if (block != 0 && block != 128 && block != 256) return fail(DPX_ERR_ARG, "block must be 128 or 256");
     if (vecs != 0 && vecs != 1 && vecs != 2) return fail(DPX_ERR_ARG, "vecs must be 1 or 2");
-    if (variant < 0 || variant > 6) return fail(DPX_ERR_ARG, "variant out of range");
     if (block) ctx->block = block;
     if (vecs) ctx->vecs = vecs;
     if (block || vecs) ctx->geom_auto = false;

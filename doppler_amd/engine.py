@@ -66,7 +66,8 @@ class Context:
         return self._h
 
     def set_tuning(self, block=0, vecs=0, variant=3):
-        """block: lanes per workgroup (128/256); vecs: 4-sample groups per lane (1/2/4);
+        """block: lanes per workgroup (128/256); vecs: 4-sample groups per lane (1/2); 0 keeps the current value,
+        block = vecs = -1 returns to the geometry chosen per launch (the default until one is named);
         variant: 3 auto, 1 sincos per sample, 2 tabulated correctors. Applies to plans created afterwards."""
         check(self._lib.dpx_set_tuning(self._h, block, vecs, variant))
 

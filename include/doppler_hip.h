@@ -266,7 +266,7 @@ int dpx_debug_copy(dpx_ctx *ctx, const void *d_in, void *d_out, size_t n_bytes, 
  * block / vecs: tile-kernel geometry, lanes per workgroup (128 or 256) and 4-sample groups
  *          per lane (1 or 2); the rows kernel always runs one wavefront x 2 rows.  Until a call names one,
  *          every launch picks 256 x 1 or 128 x 2 (the same 1024-sample tile) from its output format and
- *          whether the plan has tile tables (measured: DESIGN.md section 4).
+ *          whether the plan has tile tables (measured: DESIGN.md section 4); block = vecs = -1 returns to that.
  * variant: 3 = auto: correctors tabulated wherever a period repeats at least twice; rows kernel for up to
  *              eight long stretches (const mode), walk kernel for more (track mode), tile kernel for the rest;
  *          1 = sincos per sample wherever the period allows it (>= 4);

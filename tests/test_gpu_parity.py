@@ -272,7 +272,7 @@ def test_const_stream_bulk_vs_oracle(ctx, orc, intype, outtype):
             assert fin == sn_w
             assert_same_bytes(got, want, outtype, "variant=%d block=%d vecs=%d" % (variant, block, vecs))
     finally:
-        ctx.set_tuning(128, 2, 3)
+        ctx.set_tuning(-1, -1, 3)     # back to the geometry chosen per launch
 
 
 @pytest.mark.parametrize("shift,rate", [(815000.0, 2400000), (9876.543, 1024000), (-5234.17, 1024000), (3.0, 1024000),
@@ -289,6 +289,27 @@ def test_periods_and_large_angles_bulk(ctx, orc, shift, rate):
         got, fin = run_bulk(ctx, x, intype, outtype, [(n, shift)], rate)
         assert fin == sn_w
         assert_same_bytes(got, want, outtype, "shift=%r %s->%s" % (shift, intype, outtype))
+
+
+@pytest.mark.parametrize("shift,rate", [(5001.0, 1024000), (3.0, 1024000), (-7777.77, 1024000), (1.0e9, 1000), (0.001, 1024000)])
+def test_sincos_per_sample_paths_known_per_tile(ctx, orc, shift, rate):
+    """sincos per sample (variant 1): a tile that does not wrap takes sincosf's argument path from the stretch's three
+    counters (first n with |theta| >= 2^-12 / 120 / 2^33, bisected by the planner) instead of looking at its angles.
+    The shifts put those counters inside the stream (5001 Hz: n = 4 and 3910), beyond it (0.001 Hz: never plain), or
+    make |theta| pass 2^33 (1e9 Hz at 1 ksps); every format pair, with the geometry chosen per launch."""
+    n = 300000 + 7
+    try:
+        ctx.set_tuning(-1, -1, 1)
+        for intype, outtype in (("i16", "i16"), ("f32", "f32"), ("i16", "f32"), ("f32", "i16")):
+            x = make_iq(intype, n, 77)
+            cx = orc.convert_iqi16_to_complex(x) if intype == "i16" else orc.convert_iqf32_to_complex(x)
+            o, sn_w = orc.shift_frequency(cx, 0, shift, rate)
+            want = orc.pack_i16(o) if outtype == "i16" else orc.pack_f32(o)
+            got, fin = run_bulk(ctx, x, intype, outtype, [(n, shift)], rate)
+            assert fin == sn_w
+            assert_same_bytes(got, want, outtype, "per sample, shift=%r %s->%s" % (shift, intype, outtype))
+    finally:
+        ctx.set_tuning(-1, -1, 3)
 
 
 def test_track_segments_bulk_vs_oracle(ctx, orc):

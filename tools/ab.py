@@ -196,7 +196,7 @@ def main():
         if (ot, "out", n) not in bufs:
             bufs[(ot, "out", n)] = torch.empty(n * BPS[ot], dtype=torch.uint8, device=dev)
         built.append(dict(name=name, pair=pair, variant=variant, opts=opts, geom=(block, vecs), plan=plan, n=n, it=it, ot=ot, lay=lay, ms=[]))
-    ctx.set_tuning(128, 2, 3)
+    ctx.set_tuning(-1, -1, 3)
     ctx.set_options()
     for b in built:        # warm-up
         x, o = bufs[(b["it"], "in", b["n"])], bufs[(b["ot"], "out", b["n"])]
