@@ -135,6 +135,7 @@ dpx::PlanTuning tuning_of(const dpx_options *o)
     t.rows_mult = o->rows_mult;
     t.rows_maxl = o->rows_maxl;
     t.rows_r = o->rows_r;
+    t.rows_compute = o->rows_compute;
     t.walk_waves = o->walk_waves;
     t.walk_rows = o->walk_rows;
     t.walk_compute = o->walk_compute;

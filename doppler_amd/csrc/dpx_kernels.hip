@@ -206,14 +206,16 @@ template <int IN_FMT, int OUT_FMT> struct RowVec {
 // Argument order matters: the first 16 dwords are preloaded into SGPRs at wavefront
 // launch (-amdgpu-kernarg-preload-count=16), and they are exactly what the matrix
 // path needs — a one-shot wavefront issues its loads without waiting for any s_load.
-template <int IN_FMT, int OUT_FMT, bool FMA, int R>
+template <int IN_FMT, int OUT_FMT, bool FMA, int R, bool COMPUTE>
 __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restrict__ in,
                                                           uint8_t *__restrict__ out,
                                                           const float2 *__restrict__ tab,   // table, origin = sample A
                                                           uint64_t A, uint32_t L, uint32_t cols,
                                                           uint64_t div_m, uint32_t div_s,
                                                           uint32_t n_extra, uint32_t P,
-                                                          // ---- ragged path only (not preloaded)
+                                                          float ratio,                       // COMPUTE only
+                                                          // ---- not preloaded
+                                                          uint32_t idx0,                     // COMPUTE only
                                                           const DevSeg *__restrict__ segs,
                                                           RowsArgs ra)
 {
@@ -243,10 +245,39 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
         // wraps), origin = sample A; the row length is a multiple of the period, so the index is the column
         // modulo the period — the column itself when a row is exactly one period (the headline case).
         const uint32_t e0 = (L == P) ? cs0 : cs0 % P;
-        const u32x4 *tp = reinterpret_cast<const u32x4 *>(tab + e0);
         u32x4 t[S / 2];
+        if constexpr (COMPUTE) {
+            // the same S (cos, sin) pairs, evaluated here: counter of column c = ((idx0 + c) mod P) + 1, P >= 4
+            uint32_t e = idx0 + e0;
+            e = e >= P ? e - P : e;
+            uint32_t n[S];
 #pragma unroll
-        for (int i = 0; i < S / 2; ++i) t[i] = tp[i];
+            for (int k = 0; k < S; ++k) {
+                const uint32_t ek = e + (uint32_t)k;
+                n[k] = (ek >= P ? ek - P : ek) + 1u;
+            }
+            if constexpr (S == 4) {
+                f32x2 cs[4];
+                corrector4<FMA>(ratio, n, cs);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    t[k >> 1][(k & 1) * 2] = __float_as_uint(cs[k].x);
+                    t[k >> 1][(k & 1) * 2 + 1] = __float_as_uint(cs[k].y);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    float c, sn;
+                    corrector<FMA>(ratio, n[k], c, sn);
+                    t[k >> 1][(k & 1) * 2] = __float_as_uint(c);
+                    t[k >> 1][(k & 1) * 2 + 1] = __float_as_uint(sn);
+                }
+            }
+        } else {
+            const u32x4 *tp = reinterpret_cast<const u32x4 *>(tab + e0);
+#pragma unroll
+            for (int i = 0; i < S / 2; ++i) t[i] = tp[i];
+        }
 
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -934,13 +965,15 @@ static int rows_t(const void *d_in, void *d_out, const DevSeg *d_segs, const voi
     const uint64_t M = ((1ull << sh) + cols - 1) / cols;
     const dim3 grid((uint32_t)(n_main + n_extra));
     const float2 *tab = lut + r.tab_off;
-#define DPX_ROWS_CASE(RR)                                                                                                                   \
-    if (r.R == RR) {                                                                                                                        \
-        if (fma) rows_kernel<IN_FMT, OUT_FMT, true, RR><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_extra, r.P, d_segs, r);  \
-        else     rows_kernel<IN_FMT, OUT_FMT, false, RR><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_extra, r.P, d_segs, r); \
+    // table or evaluation: the plan allows both for long periods, the formats decide (dpx_planner.cpp, kRowsComputeMinP)
+    const bool comp = r.compute == 2 || (r.compute == 1 && IN_FMT == DPX_FMT_I16 && OUT_FMT == DPX_FMT_I16);
+#define DPX_ROWS_CASE(RR, CC)                                                                                                               \
+    if (r.R == RR && comp == CC) {                                                                                                           \
+        if (fma) rows_kernel<IN_FMT, OUT_FMT, true, RR, CC><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_extra, r.P, r.ratio, r.idx0, d_segs, r);  \
+        else     rows_kernel<IN_FMT, OUT_FMT, false, RR, CC><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_extra, r.P, r.ratio, r.idx0, d_segs, r); \
         return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                                                      \
     }
-    DPX_ROWS_CASE(2) DPX_ROWS_CASE(4) DPX_ROWS_CASE(8)
+    DPX_ROWS_CASE(2, false) DPX_ROWS_CASE(4, false) DPX_ROWS_CASE(8, false) DPX_ROWS_CASE(4, true) DPX_ROWS_CASE(8, true)
 #undef DPX_ROWS_CASE
     return DPX_ERR_ARG;
 }

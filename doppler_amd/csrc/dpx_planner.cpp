@@ -291,10 +291,30 @@ uint32_t pick_row_length(uint32_t P, uint64_t body, uint32_t R, const PlanTuning
 
 // rows per wavefront: 2 while one period of correctors stays L1/L2-hot, 4 for large tables
 // (measured, GB/s at R = 2 / 4 / 8: 8 KB table 6615 / 6264 / 6194; 876 KB table 5406 / 5660 / 5777)
-uint32_t pick_rows_per_wave(uint32_t P, const PlanTuning &tn)
+// Rows of 8192 or 16384 samples (the two rows of a wavefront 32 or 64 KiB apart) run 3 points faster than any other
+// length (83.7 / 84.3 % against 80.1-81.7 % for L = 4096 ... 131072 with the headline's own table: `tools/ab.py --set
+// rowlen`), which needs a period that divides 16384.  Every other period pays, on top, for its table: one period is read by
+// every wavefront of the launch, 8 bytes per R samples beside the 8 bytes of stream an i16 -> i16 sample moves.  From
+// kRowsComputeMinP on such a launch may instead let every wavefront evaluate its columns' correctors itself, once for its
+// 4 rows: P = 5120 / 6400 / 10 240 / 20 480 / 1 024 000: +1.0 / +1.1 / +1.4 / +1.5 / +3.5 points for i16 -> i16, no gain
+// for the pairs with an f32 side (16 or 12 bytes of stream per sample; profiles/r02_walk.md section 7).  The plan does not
+// know the formats, so such a launch carries both — the table and (ratio, idx0) — and launch_rows picks per format pair.
+constexpr uint32_t kRowsComputeMinP = 2049;
+
+// 0: table only; 1: i16 -> i16 evaluates, the other pairs read the table; 2: every pair evaluates (measurement)
+uint32_t rows_compute(uint32_t P, const PlanTuning &tn)
+{
+    if (P < 4) return 0;
+    if (tn.rows_compute == 1) return 2;
+    return P >= (tn.rows_compute ? tn.rows_compute : kRowsComputeMinP) ? 1 : 0;
+}
+
+uint32_t pick_rows_per_wave(uint32_t P, const PlanTuning &tn, uint32_t compute)
 {
     uint32_t R = ((uint64_t)P + 3) * 8 <= (128u << 10) ? 2 : 4;
-    if (tn.rows_r) R = tn.rows_r;                                              // measurement override
+    if (compute) R = 4;                                    // measured best for both ways (tables of such periods: 2 -> 4 is +1)
+    if (tn.rows_r) R = tn.rows_r;                          // measurement override
+    if (compute && R == 2) R = 4;                          // the evaluating kernel is built for 4 and 8 rows
     return (R == 2 || R == 4 || R == 8) ? R : 2;
 }
 
@@ -381,25 +401,35 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
     // rows kernel: one launch per stretch, the fastest shape for a long stretch (const mode);
     // walk kernel: any number of stretches in one launch (track mode: one stretch per second of stream);
     // tile kernel: whatever is left, and everything when neither of the above applies.
-    auto rows_geometry = [&](const DevSeg &s, uint64_t *A, uint32_t *R, uint32_t *L) {
+    auto rows_geometry = [&](const DevSeg &s, uint64_t *A, uint32_t *R, uint32_t *L, uint32_t *compute = nullptr) {
         if (s.lut_len == 0 || s.count < kRowsMinSamples) return false;
         const uint64_t end = s.first + s.count;
         // matrix origin on a 256-sample boundary: 1 KiB of i16 / 2 KiB of f32 per wavefront, aligned
         *A = (s.first + 255) & ~255ull;
         if (*A >= end) return false;
-        *R = pick_rows_per_wave(s.period, tn);
+        uint32_t comp = rows_compute(s.period, tn);
+        *R = pick_rows_per_wave(s.period, tn, comp);
         *L = pick_row_length(s.period, end - *A, *R, tn);
+        if (comp == 1 && *L != 0 && *L % 8192 == 0 && *L <= 16384) {       // the fast row lengths: table, two rows
+            comp = 0;
+            *R = pick_rows_per_wave(s.period, tn, 0);
+            *L = pick_row_length(s.period, end - *A, *R, tn);
+        }
+        if (compute) *compute = comp;
         return *L != 0;
     };
     bool use_rows = false, use_walk = false;
     if (choice == kChooseAuto || choice == kChooseRows) {
-        size_t eligible = 0;
+        // a plan of a few long tabulated stretches (const mode) is a rows plan; one of many (track mode: a stretch per
+        // second of stream) belongs to the walk kernel whatever rows geometry its stretches would allow
+        size_t eligible = 0, long_tabulated = 0;
         for (const DevSeg &s : plan.segs) {
             uint64_t A;
             uint32_t R, L;
             if (rows_geometry(s, &A, &R, &L)) ++eligible;
+            if (s.lut_len != 0 && s.count >= kRowsMinSamples) ++long_tabulated;
         }
-        use_rows = eligible > 0 && eligible <= kRowsMaxLaunches;
+        use_rows = eligible > 0 && long_tabulated <= kRowsMaxLaunches;
     }
     if ((choice == kChooseAuto && !use_rows) || choice == kChooseWalk) {
         uint64_t in_matrices = 0, n_wg = 0;
@@ -444,7 +474,8 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         DevSeg &s = plan.segs[i];
         uint64_t A;
         uint32_t R, L;
-        if (to_walk[i] || !rows_geometry(s, &A, &R, &L)) continue;
+        uint32_t comp = 0;
+        if (to_walk[i] || !rows_geometry(s, &A, &R, &L, &comp)) continue;
         const uint64_t end = s.first + s.count;
         const uint64_t n_rg = (end - A) / ((uint64_t)R * L);
         s.flags |= kSegRows;
@@ -462,6 +493,10 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         ln.rows.r1 = (end - ln.rows.B <= kAbsorbMax) ? end : ln.rows.B;
         ln.rows.seg_lo = (uint32_t)i;
         ln.rows.n_segs = (uint32_t)ns;
+        ln.rows.compute = comp;
+        ln.rows.idx0 = counter_at(s, A - s.first) - 1u;
+        ln.rows.ratio = s.ratio;
+        ln.rows.pad = 0;
         // table: one period (+3 so that four consecutive entries never wrap), origin = sample A
         ln.rows.tab_off = (uint32_t)pool;
         plan.tables.push_back({pool, s.period, counter_at(s, A - s.first), s.period + 3, s.ratio});
@@ -720,15 +755,18 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
             const RowsArgs &r = ln.rows;
             const DevSeg &s = plan.segs[0];
             (void)s;
-            // the table this launch reads: entry e -> ((n_first - 1 + e) mod P) + 1
+            // the table this launch reads: entry e -> ((n_first - 1 + e) mod P) + 1; a launch that evaluates instead
+            // uses the same counters, from idx0 — the two must agree
             const TableBuild *tb = nullptr;
             for (const TableBuild &t : plan.tables) if (t.off == r.tab_off) tb = &t;
+            if (r.compute && (r.idx0 != tb->n_first - 1u || r.P != tb->period)) put(0, 0xfffffff9u);
+            const uint32_t first_idx = tb->n_first - 1u, period = tb->period;
             for (uint64_t rg = 0; rg < r.n_rg; ++rg)
                 for (uint32_t row = 0; row < r.R; ++row)
                     for (uint32_t cs = 0; cs < r.L; ++cs) {
                         const uint64_t g = r.A + (rg * r.R + row) * (uint64_t)r.L + cs;
                         const uint32_t e = (r.L == r.P) ? cs : cs % r.P;          // the kernel's table index
-                        put(g, (uint32_t)(((uint64_t)(tb->n_first - 1u) + e) % tb->period) + 1u);
+                        put(g, (uint32_t)(((uint64_t)first_idx + e) % period) + 1u);
                     }
             for (uint64_t g = r.r0; g < r.A; ++g) generic(r.seg_lo, g);
             for (uint64_t g = r.B; g < r.r1; ++g) generic(r.seg_lo, g);

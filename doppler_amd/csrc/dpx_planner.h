@@ -55,6 +55,8 @@ struct PlanTuning {
     uint32_t rows_r = 0;         // rows kernel: rows per wavefront (2, 4 or 8)
     uint32_t walk_waves = 0;     // walk kernel: wavefronts per workgroup (4, 5, 6 or 8) ...
     uint32_t walk_rows = 0;      // ... and rows per wavefront (2)
+    uint32_t rows_compute = 0;   // rows kernel: periods from this many samples on are evaluated in the kernel (0 = the
+                                 // planner's default, 0xffffffff = never, 1 = always)
     uint64_t walk_tilemin = 0;   // walk plans: an uncovered gap at least this long gets its own tile launch
     int walk_compute = -1;       // walk kernel: 1 = workgroups always evaluate their corrector slices, 0 = always read
                                  // plan-time tables, -1 = per matrix: tables from walk_table_rows rows on

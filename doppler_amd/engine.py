@@ -72,7 +72,7 @@ class Context:
         check(self._lib.dpx_set_tuning(self._h, block, vecs, variant))
 
     def set_options(self, **opts):
-        """Kernel-shape knobs (dpx_options: rows_mult, rows_maxl, rows_r, walk_waves, walk_rows, walk_compute,
+        """Kernel-shape knobs (dpx_options: rows_mult, rows_maxl, rows_r, rows_compute, walk_waves, walk_rows, walk_compute,
         walk_tilemin); no arguments restores the defaults. Applies to plans created afterwards."""
         check(self._lib.dpx_set_options(self._h, _lib.make_options(opts)))
 

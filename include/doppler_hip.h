@@ -124,7 +124,9 @@ typedef struct dpx_options {
     int32_t walk_compute;    /* walk kernel: 1 = workgroups always evaluate their corrector slices, 0 = always plan-time tables,
                               * -1 = per matrix (tables for matrices of at least walk_table_rows rows) */
     uint32_t walk_table_rows; /* that threshold */
-    uint32_t reserved;
+    uint32_t rows_compute;   /* rows kernel: for periods of at least this many samples an i16 -> i16 launch leaves the table alone,
+                              * its wavefronts evaluate their columns' correctors (0 = the planner's threshold, 0xffffffff = never,
+                              * 1 = always and for every format pair) */
     uint64_t walk_tilemin;   /* walk plans: uncovered gaps at least this long (samples) get a tile-kernel launch */
 } dpx_options;
 /* applies to plans created afterwards; NULL restores the defaults */

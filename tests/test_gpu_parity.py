@@ -413,6 +413,35 @@ def test_walk_kernel_workgroup_shapes_and_on_the_fly_slices(ctx, orc, waves, max
         ctx.set_tuning(0, 0, 3)
 
 
+@pytest.mark.parametrize("rows_compute,rows_r", [(1, 0), (1, 8), (0, 0), (0xffffffff, 0)])
+def test_rows_kernel_evaluates_its_correctors(ctx, orc, rows_compute, rows_r):
+    """Rows launches that leave their table alone: every wavefront evaluates the correctors of its columns for its 4 (8)
+    rows.  rows_compute = 1 forces that for every format pair, 0 is the planner's rule (i16 -> i16 and periods that do not
+    give 8192- or 16384-sample rows), 0xffffffff never.  Periods: 10240 (rows of one period), 2592 and 480 (rows of several
+    periods: the column index wraps inside a row), 6400; a stream that starts mid-period (the counter carried in)."""
+    import doppler_amd
+    cases = [((100.0, 1024000), 0), ((9876.543, 1024000), 0), ((815000.0, 2400000), 77), ((160.0, 1024000), 3001)]
+    n = (1 << 21) + 4321
+    opts = dict(rows_compute=rows_compute, rows_r=rows_r)
+    ctx.set_tuning(0, 0, 6)
+    ctx.set_options(**opts)
+    try:
+        for (shift, rate), sn0 in cases:
+            lay = doppler_amd.plan_layout([(n, shift)], rate, sn0, variant=6, options=opts)
+            assert lay["rows_launches"] == 1 and lay["walk_launches"] == 0, lay
+            for intype, outtype in (("i16", "i16"), ("f32", "i16"), ("i16", "f32"), ("f32", "f32")):
+                x = make_iq(intype, n, 4100 + sn0, full_scale=True)
+                cx = orc.convert_iqi16_to_complex(x) if intype == "i16" else orc.convert_iqf32_to_complex(x)
+                o, sn_w = orc.shift_frequency(cx, sn0, shift, rate)
+                want = orc.pack_i16(o) if outtype == "i16" else orc.pack_f32(o)
+                got, fin = run_bulk(ctx, x, intype, outtype, [(n, shift)], rate, sn0)
+                assert fin == sn_w
+                assert_same_bytes(got, want, outtype, "rows, rows_compute=%d R=%d shift=%r %s->%s" % (rows_compute, rows_r, shift, intype, outtype))
+    finally:
+        ctx.set_options()
+        ctx.set_tuning(0, 0, 3)
+
+
 def test_walk_kernel_plans_with_on_the_fly_slices(ctx, orc):
     """The plan shapes of test_walk_kernel_plans_vs_oracle and test_walk_kernel_random_plans again with walk_compute=1
     (no corrector tables at all)."""

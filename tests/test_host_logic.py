@@ -103,6 +103,21 @@ def test_launch_lists_cover_every_sample_once(orc):
                 assert np.array_equal(c, want), (segs, variant, block, vecs, np.flatnonzero(c != want)[:5])
 
 
+def test_rows_launches_that_evaluate_their_correctors(orc):
+    """A rows launch of a long period carries its table AND (ratio, idx0), and launch_rows decides from the formats which
+    to use; the host mirror checks that both name the same counters (0xfffffff9 otherwise) — for rows of one period, rows
+    of several periods, a counter carried in, 4 and 8 rows per wavefront, the planner's own rule and the overrides."""
+    cases = [([(1 << 21, 100.0)], 1024000, 0), ([(1 << 20, 9876.543)], 1024000, 0), ([(900000, 815000.0)], 2400000, 77),
+             ([(1 << 21, 160.0)], 1024000, 3001), ([(600000, 250.0), (3000000, 50.0)], 1024000, 5)]
+    for segs, rate, sn0 in cases:
+        want, _ = oracle_counters(orc, segs, rate, sn0)
+        for opts in (dict(), dict(rows_compute=1), dict(rows_compute=1, rows_r=8), dict(rows_compute=0xffffffff), dict(rows_compute=5000)):
+            lay = doppler_amd.plan_layout(segs, rate, sn0, 128, 2, 6, options=opts)
+            assert lay["rows_launches"] == len(segs), (segs, opts, lay)
+            c, w = doppler_amd.plan_simulate(segs, rate, sn0, 128, 2, 6, options=opts)
+            assert (w == 1).all() and np.array_equal(c, want), (segs, opts, np.flatnonzero(c != want)[:5])
+
+
 def test_walk_kernel_plans(orc):
     """Track-shaped plans (many constant-shift segments, counters carried across): more than eight tabulated
     stretches sends the plan to the walk kernel (one launch: matrices with 32-sample-aligned shifted rows, leftover
@@ -123,6 +138,7 @@ def test_walk_kernel_plans(orc):
         assert sum(lay[k] for k in ("rows_samples", "walk_samples", "tile_samples", "single_samples")) == lay["n_samples"]
         if i < 3:    # these really are walk-kernel plans: matrices, leftover ranges, and (first plan) tile launches
             assert lay["walk_launches"] == 1 and lay["walk_matrices"] >= 8 and lay["leftover_ranges"] > 0, lay
+            assert lay["rows_launches"] == 0, lay      # many tabulated stretches: never a rows plan, whatever their geometry
         for variant in (3, 5):
             c, w = doppler_amd.plan_simulate(segs, rate, sn0, 128, 2, variant)
             assert (w == 1).all(), (segs[:3], variant, np.flatnonzero(w != 1)[:5], w[np.flatnonzero(w != 1)[:5]])

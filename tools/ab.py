@@ -72,6 +72,34 @@ def cases(which):
             for pair in ("i16:i16", "f32:f32", "f32:i16"):
                 for variant in (6, 5):
                     c.append(("const %g Hz @%d" % (shift, rate), lambda f, s=shift: const_segs(s), pair, variant, dict(_rate=rate)))
+    if which == "bigshape":      # long periods rich in factors of two (rows of one column share their low address bits)
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for shift in (3, 10):
+            c.append(("const %g Hz rows" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 6, {}))
+            for r in (2, 8):
+                c.append(("const %g Hz rows" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 6, dict(rows_r=r)))
+            for waves, rows in ((5, 2), (4, 2), (2, 2), (4, 1), (8, 1), (8, 2), (5, 4), (3, 1)):
+                c.append(("const %g Hz walk" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 5, dict(walk_waves=waves, walk_rows=rows)))
+    if which == "rcomp":         # rows kernel: plan-time table against correctors evaluated per wavefront for 8 (4) rows
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        NEVER = 0xffffffff
+        for shift in (3, 10, 25, 100, 9876.543, 5000):
+            for pair in ("i16:i16", "f32:f32", "f32:i16", "i16:f32"):
+                c.append(("const %g Hz rows table" % shift, lambda f, s=shift: const_segs(s), pair, 6, dict(rows_compute=NEVER)))
+                c.append(("const %g Hz rows compute" % shift, lambda f, s=shift: const_segs(s), pair, 6, dict(rows_compute=1)))
+                c.append(("const %g Hz rows compute" % shift, lambda f, s=shift: const_segs(s), pair, 6, dict(rows_compute=1, rows_r=4)))
+    if which == "rthresh":       # from which period on evaluating beats the table (i16 -> i16)
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        NEVER = 0xffffffff
+        for shift, rate in ((815000, 2400000), (5000, RATE), (2500, RATE), (9876.543, RATE), (250, RATE), (200, RATE), (160, RATE), (125, RATE), (100, RATE), (50, RATE), (3, RATE))[int(os.environ.get("AB_FROM", "0")):]:
+            c.append(("const %g Hz table" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 6, dict(rows_compute=NEVER, _rate=rate)))
+            c.append(("const %g Hz table" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 6, dict(rows_compute=NEVER, rows_r=4, _rate=rate)))
+            c.append(("const %g Hz compute" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 6, dict(rows_compute=1, _rate=rate)))
+            c.append(("const %g Hz default" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 3, dict(_rate=rate)))
+            c.append(("const %g Hz default" % shift, lambda f, s=shift: const_segs(s), "f32:i16", 3, dict(_rate=rate)))
+    if which == "rowlen":        # row length alone: the headline's period (1024) with L = mult x 1024, table, 2 rows per wavefront
+        for mult in (4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 20, 24, 25, 32, 40, 48, 64, 128):
+            c.append(("const 5000 Hz L=%d" % (mult * 1024), lambda f: const_segs(5000), "i16:i16", 6, dict(rows_mult=mult, rows_compute=0xffffffff)))
     if which == "waves":
         c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
         for waves in (2, 3, 4, 5, 6, 8):
@@ -166,7 +194,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
