@@ -100,6 +100,12 @@ def cases(which):
     if which == "rowlen":        # row length alone: the headline's period (1024) with L = mult x 1024, table, 2 rows per wavefront
         for mult in (4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 20, 24, 25, 32, 40, 48, 64, 128):
             c.append(("const 5000 Hz L=%d" % (mult * 1024), lambda f: const_segs(5000), "i16:i16", 6, dict(rows_mult=mult, rows_compute=0xffffffff)))
+    if which == "rowlen2":       # row length near 8192 in steps of 32 samples (period 32: 32 kHz at 1.024 Msps)
+        for L in (8192 - 1024, 8192 - 256, 8192 - 64, 8192 - 32, 8192, 8192 + 32, 8192 + 64, 8192 + 256, 8192 + 1024, 16384 - 32, 16384, 16384 + 32, 16384 + 2048, 24576, 32768, 2048, 4096):
+            c.append(("const 32 kHz L=%d" % L, lambda f: const_segs(32000), "i16:i16", 6, dict(rows_mult=L // 32, rows_compute=0xffffffff)))
+        for L in (8192, 16384, 10240):
+            for r in (4, 8):
+                c.append(("const 32 kHz L=%d" % L, lambda f: const_segs(32000), "i16:i16", 6, dict(rows_mult=L // 32, rows_r=r, rows_compute=0xffffffff)))
     if which == "waves":
         c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
         for waves in (2, 3, 4, 5, 6, 8):
@@ -194,7 +200,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
