@@ -53,6 +53,10 @@ def cases(which):
             for comp in (0, 1):
                 for waves in (5,):
                     c.append(("synth %d rows of P=65536" % rows, lambda f, r=rows: synth_segs(r), "i16:i16", 3, dict(walk_compute=comp, walk_waves=waves)))
+    if which == "synth2":        # chunking policy per matrix height: (wavefronts, most rows per wavefront)
+        for rows in (3, 5, 7, 9, 10, 12, 14, 17, 20, 25):
+            for waves, mr in ((4, 2), (4, 3), (4, 4), (5, 2), (5, 3), (3, 2), (3, 4)):
+                c.append(("synth %d rows of P=65536" % rows, lambda f, r=rows: synth_segs(r, total=307200000), "i16:i16", 3, dict(walk_waves=waves, walk_rows=mr)))
     if which == "size":
         for n in (268435456, 614400000, 1073741824):
             c.append(("const 5000 Hz n=%d" % n, lambda f, n=n: const_segs(5000, n), "i16:i16", 3, {}))
@@ -200,7 +204,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
