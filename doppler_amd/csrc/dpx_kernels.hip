@@ -34,11 +34,26 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // ---------------------------------------------------------------- sample math
 
 // dsp.rs:92-93: ((hi as i16) << 8 | lo as i16) as f32 / 32768.  (exact: power of two)
+//
+// RAW (the fused i16 -> i16 path only): the division is left out here and folded into the constant of the pack below.
+// Scaling by 2^-15 is exact and commutes with every rounding in between (the two products and the sum of the mix, each
+// rounded on its own): with I, Q the integers, fl(fl(I c) - fl(Q s)) 2^-15 IS the reference's fl(fl(I' c) - fl(Q' s)) for
+// I' = I 2^-15, and fl(X 2^-15 * 32767) = fl(X * (32767 * 2^-15)) — the same real product, rounded once, the constant
+// exact in f32.  Only below 2^-126 (a denormal intermediate: |corrector| < 2^-111) could the two differ, and such a value
+// truncates to the i16 0 either way.  One packed multiply less per sample.
+template <bool RAW = false>
 __device__ __forceinline__ void unpack_i16(uint32_t w, float &re, float &im)
 {
-    re = (float)(int16_t)(w & 0xffffu) * 0x1p-15f;
-    im = (float)(int16_t)(w >> 16) * 0x1p-15f;
+    if constexpr (RAW) {
+        re = (float)(int16_t)(w & 0xffffu);
+        im = (float)(int16_t)(w >> 16);
+    } else {
+        re = (float)(int16_t)(w & 0xffffu) * 0x1p-15f;
+        im = (float)(int16_t)(w >> 16) * 0x1p-15f;
+    }
 }
+// the i16 -> i16 pair computes on the unscaled integers
+template <int IN_FMT, int OUT_FMT> constexpr bool kRawI16 = IN_FMT == DPX_FMT_I16 && OUT_FMT == DPX_FMT_I16;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -74,9 +89,11 @@ __device__ __forceinline__ int f32_as_i32_sat(float x)
 }
 
 // main.rs:77-83: i = (re * 32767.0) as i16, little-endian I then Q.
+template <bool RAW = false>
 __device__ __forceinline__ uint32_t pack_i16(float re, float im)
 {
-    const f32x2 sc = f32x2{re, im} * 32767.0f;           // one v_pk_mul_f32, each product rounded on its own
+    constexpr float K = RAW ? 0x1.fffcp-1f /* 32767 / 32768, exact */ : 32767.0f;
+    const f32x2 sc = f32x2{re, im} * K;                  // one v_pk_mul_f32, each product rounded on its own
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     const s16x2 p = __builtin_amdgcn_cvt_pk_i16(f32_as_i32_sat(sc.x), f32_as_i32_sat(sc.y));
     return __builtin_bit_cast(uint32_t, p);
@@ -107,22 +124,22 @@ __device__ __forceinline__ void store_quad(uint8_t *base, uint64_t g, const Quad
     for (int i = 0; i < Fmt<FMT>::kVecs; ++i) __builtin_nontemporal_store(q.v[i], p + i);
 }
 
-template <int FMT>
+template <int FMT, bool RAW = false>
 __device__ __forceinline__ void quad_get(const Quad<FMT> &q, int k, float &re, float &im)
 {
     if constexpr (FMT == DPX_FMT_I16) {
-        unpack_i16(q.v[0][k], re, im);
+        unpack_i16<RAW>(q.v[0][k], re, im);
     } else {   // dsp.rs:108-109: the bytes ARE the f32
         re = __uint_as_float(q.v[k >> 1][(k & 1) * 2]);
         im = __uint_as_float(q.v[k >> 1][(k & 1) * 2 + 1]);
     }
 }
 
-template <int FMT>
+template <int FMT, bool RAW = false>
 __device__ __forceinline__ void quad_set(Quad<FMT> &q, int k, float re, float im)
 {
     if constexpr (FMT == DPX_FMT_I16) {
-        q.v[0][k] = pack_i16(re, im);
+        q.v[0][k] = pack_i16<RAW>(re, im);
     } else {   // main.rs:91: raw reinterpret
         q.v[k >> 1][(k & 1) * 2] = __float_as_uint(re);
         q.v[k >> 1][(k & 1) * 2 + 1] = __float_as_uint(im);
@@ -130,11 +147,11 @@ __device__ __forceinline__ void quad_set(Quad<FMT> &q, int k, float re, float im
 }
 
 // one sample at a time: ragged tiles and stretch boundaries only
-template <int FMT>
+template <int FMT, bool RAW = false>
 __device__ __forceinline__ void load_one(const uint8_t *base, uint64_t g, float &re, float &im)
 {
     if constexpr (FMT == DPX_FMT_I16) {
-        unpack_i16(*reinterpret_cast<const uint32_t *>(base + g * 4), re, im);
+        unpack_i16<RAW>(*reinterpret_cast<const uint32_t *>(base + g * 4), re, im);
     } else {
         const u32x2 w = *reinterpret_cast<const u32x2 *>(base + g * 8);
         re = __uint_as_float(w[0]);
@@ -142,11 +159,11 @@ __device__ __forceinline__ void load_one(const uint8_t *base, uint64_t g, float 
     }
 }
 
-template <int FMT>
+template <int FMT, bool RAW = false>
 __device__ __forceinline__ void store_one(uint8_t *base, uint64_t g, float re, float im)
 {
     if constexpr (FMT == DPX_FMT_I16) {
-        *reinterpret_cast<uint32_t *>(base + g * 4) = pack_i16(re, im);
+        *reinterpret_cast<uint32_t *>(base + g * 4) = pack_i16<RAW>(re, im);
     } else {
         u32x2 w;
         w[0] = __float_as_uint(re);
@@ -190,9 +207,9 @@ __device__ __forceinline__ void one_sample(const uint8_t *in, uint8_t *out, cons
     const DevSeg sx = segs[si];
     float c, s, a, b, re, im;
     corrector<FMA>(sx.ratio, counter_at(sx, g - sx.first), c, s);
-    load_one<IN_FMT>(in, g, a, b);
+    load_one<IN_FMT, kRawI16<IN_FMT, OUT_FMT>>(in, g, a, b);
     mix(a, b, c, s, re, im);
-    store_one<OUT_FMT>(out, g, re, im);
+    store_one<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(out, g, re, im);
 }
 
 // ---- rows kernel: one wavefront, R rows of one tabulated periodic stretch
@@ -285,7 +302,7 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
 #pragma unroll
             for (int k = 0; k < S; ++k) {
                 float a, bq;
-                if constexpr (IN_FMT == DPX_FMT_I16) unpack_i16(q[r][k], a, bq);
+                if constexpr (IN_FMT == DPX_FMT_I16) unpack_i16<kRawI16<IN_FMT, OUT_FMT>>(q[r][k], a, bq);
                 else { a = __uint_as_float(q[r][2 * k]); bq = __uint_as_float(q[r][2 * k + 1]); }
                 const float c = __uint_as_float(t[k >> 1][(k & 1) * 2]);
                 const float s = __uint_as_float(t[k >> 1][(k & 1) * 2 + 1]);
@@ -296,12 +313,12 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
                 if constexpr (S == 4) {
                     u32x4 o;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = pack_i16(re[k], im[k]);
+                    for (int k = 0; k < 4; ++k) o[k] = pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[k], im[k]);
                     __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(op));
                 } else {
                     u32x2 o;
-                    o[0] = pack_i16(re[0], im[0]);
-                    o[1] = pack_i16(re[1], im[1]);
+                    o[0] = pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[0], im[0]);
+                    o[1] = pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[1], im[1]);
                     __builtin_nontemporal_store(o, reinterpret_cast<u32x2 *>(op));
                 }
             } else {
@@ -380,9 +397,9 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
 #pragma unroll
             for (int k = 0; k < (int)SPL; ++k) {
                 float a, b, re, im;
-                quad_get<IN_FMT>(qin[v], k, a, b);
+                quad_get<IN_FMT, kRawI16<IN_FMT, OUT_FMT>>(qin[v], k, a, b);
                 mix(a, b, cs[k].x, cs[k].y, re, im);
-                quad_set<OUT_FMT>(qo, k, re, im);
+                quad_set<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(qo, k, re, im);
             }
             store_quad<OUT_FMT>(out, t0 + (uint64_t)(v * BLOCK + tid) * SPL, qo);
         }
@@ -434,9 +451,9 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
 #pragma unroll
             for (int k = 0; k < (int)SPL; ++k) {
                 float a, b, re, im;
-                quad_get<IN_FMT>(qin[v], k, a, b);
+                quad_get<IN_FMT, kRawI16<IN_FMT, OUT_FMT>>(qin[v], k, a, b);
                 mix(a, b, cs[k].x, cs[k].y, re, im);
-                quad_set<OUT_FMT>(qo, k, re, im);
+                quad_set<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(qo, k, re, im);
             }
             store_quad<OUT_FMT>(out, t0 + (uint64_t)(v * BLOCK + tid) * SPL, qo);
         }
@@ -616,26 +633,26 @@ __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_
                 const uint32_t ok = off[u] + (uint32_t)k;     // uniform: plane and base position of corrector k
                 const float2 cs = slice[(ok & (SP::kPlanes - 1)) * SP::kStride + (ok >> SP::kLog2) + (uint32_t)v * kRowsLanes + lane];
                 float a, bq;
-                if constexpr (IN_FMT == DPX_FMT_I16) unpack_i16(qin[u][v][k], a, bq);
+                if constexpr (IN_FMT == DPX_FMT_I16) unpack_i16<kRawI16<IN_FMT, OUT_FMT>>(qin[u][v][k], a, bq);
                 else { a = __uint_as_float(qin[u][v][2 * k]); bq = __uint_as_float(qin[u][v][2 * k + 1]); }
                 mix(a, bq, cs.x, cs.y, re[k], im[k]);
             }
             if constexpr (OUT_FMT == DPX_FMT_I16) {
                 if constexpr (S == 4) {
-                    u32x4 o = {pack_i16(re[0], im[0]), pack_i16(re[1], im[1]), pack_i16(re[2], im[2]),
-                               pack_i16(re[3], im[3])};
+                    u32x4 o = {pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[0], im[0]), pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[1], im[1]), pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[2], im[2]),
+                               pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[3], im[3])};
                     asm volatile("" : "+v"(o));   // keeps the vectoriser from rebuilding the store without its nt flag
                     __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(op[u][v]));
                 } else if constexpr (XP) {
                     u32x2 o;
-                    o[0] = pack_i16(re[0], im[0]);
-                    o[1] = pack_i16(re[1], im[1]);
+                    o[0] = pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[0], im[0]);
+                    o[1] = pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[1], im[1]);
                     uint32_t *xp = xpose + (wave * U + u) * kWalkWindow + (uint32_t)v * (kRowsLanes * S) + lane * S;
                     *reinterpret_cast<u32x2 *>(xp) = o;
                 } else {
                     u32x2 o;
-                    o[0] = pack_i16(re[0], im[0]);
-                    o[1] = pack_i16(re[1], im[1]);
+                    o[0] = pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[0], im[0]);
+                    o[1] = pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[1], im[1]);
                     __builtin_nontemporal_store(o, reinterpret_cast<u32x2 *>(op[u][v]));
                 }
             } else {
@@ -791,9 +808,9 @@ __device__ __forceinline__ void leftover_block(const uint8_t *__restrict__ in, u
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float a, bq, re, im;
-                quad_get<IN_FMT>(qi, k, a, bq);
+                quad_get<IN_FMT, kRawI16<IN_FMT, OUT_FMT>>(qi, k, a, bq);
                 mix(a, bq, cs[k].x, cs[k].y, re, im);
-                quad_set<OUT_FMT>(qo, k, re, im);
+                quad_set<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(qo, k, re, im);
             }
 #pragma unroll
             for (int i = 0; i < Fmt<OUT_FMT>::kVecs; ++i) {
@@ -826,9 +843,9 @@ __device__ __forceinline__ void leftover_block(const uint8_t *__restrict__ in, u
                 if (!have[k]) continue;
                 const uint32_t o = q + (uint32_t)k * 256u;
                 float a, bq, re, im;
-                load_one<IN_FMT>(in, g0 + o, a, bq);
+                load_one<IN_FMT, kRawI16<IN_FMT, OUT_FMT>>(in, g0 + o, a, bq);
                 mix(a, bq, cs[k].x, cs[k].y, re, im);
-                store_one<OUT_FMT>(out, g0 + o, re, im);
+                store_one<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(out, g0 + o, re, im);
             }
         }
         }

@@ -628,11 +628,27 @@ def test_special_values_and_degenerate_ratios(ctx, orc):
             assert_same_bytes(got, want, outtype, "specials shift=%r rate=%d out=%s" % (shift, rate, outtype))
     corners = np.array([32767, -32768, -32768, 32767, 0, -1, 1, 0, 32767, 32767, -32768, -32768], dtype=np.int16)
     xi = np.tile(corners, 1000).view(np.uint8)
-    for shift, rate in [(5000.0, 1024000), (-15000.0, 256000), (12345.678, 48000)]:
+    # The i16 -> i16 kernels keep the unscaled integers and fold / 32768 into the pack constant (exact unless an
+    # intermediate is a denormal): shifts of 1e-30 ... 1e-42 Hz make the sin side of every product tiny or denormal
+    # (theta itself is a denormal for the last two), 3.0e38 Hz makes theta overflow.  Block, bulk and per-sample paths.
+    for shift, rate in [(5000.0, 1024000), (-15000.0, 256000), (12345.678, 48000), (1e-30, 1024000), (-3e-37, 48000),
+                        (1e-39, 1), (1e-42, 1000), (3.0e38, 1)]:
         cx = orc.convert_iqi16_to_complex(xi)
-        o, _ = orc.shift_frequency(cx, 0, shift, rate)
+        o, sn_w = orc.shift_frequency(cx, 0, shift, rate)
         got, _, _ = dsp.shift_block(xi, "i16", "i16", 0, shift, rate, ctx=ctx)
-        assert_same_bytes(got, orc.pack_i16(o), "i16", "i16 corners (saturating cast)")
+        assert_same_bytes(got, orc.pack_i16(o), "i16", "i16 corners (saturating cast), shift=%r" % shift)
+    big = np.tile(corners, 30000).view(np.uint8)                # 360 000 samples: the bulk kernels
+    for shift, rate in [(1e-30, 1024000), (1e-42, 1000), (7.0, 1024000)]:
+        cx = orc.convert_iqi16_to_complex(big)
+        o, sn_w = orc.shift_frequency(cx, 0, shift, rate)
+        for variant in (3, 1):
+            ctx.set_tuning(0, 0, variant)
+            try:
+                got, fin = run_bulk(ctx, big, "i16", "i16", [(big.size // 4, shift)], rate)
+            finally:
+                ctx.set_tuning(0, 0, 3)
+            assert fin == sn_w
+            assert_same_bytes(got, orc.pack_i16(o), "i16", "i16 corners bulk, shift=%r variant=%d" % (shift, variant))
 
 
 def test_random_cases_against_oracle(ctx, orc):
