@@ -1,5 +1,6 @@
 // Host-only fuzz of the planner (csrc/dpx_planner.cpp), built with -fsanitize=address,undefined by `make planner-fuzz`:
-// random const- and track-shaped segment lists -> plan_append -> finalize (every KernelChoice) -> simulate; every sample
+// random const- and track-shaped segment lists -> plan_append -> finalize (every KernelChoice, two thirds of the cases with
+// the PlanTuning knobs turned) -> simulate; every sample
 // must be produced exactly once with the counter of the sequential rule (dsp.rs:125-130), and the sanitizers must stay
 // silent (the hint / sentinel scans index vectors by hand).
 #include <stdint.h>
@@ -67,7 +68,19 @@ int main(int argc, char **argv)
             uint32_t sn = sn0;
             for (auto &sg : segs) dpx::plan_append(plan, dpx::ratio_of(sg.second, rate), sg.first, sn, 0);
             const uint32_t tile = (c & 1) ? 1024 : 512;
-            dpx::finalize(plan, tile, choice);
+            // every third case with the measurement knobs turned: they change launch shapes, never counters
+            dpx::PlanTuning tn;
+            if (c % 3 == 1) {
+                tn.rows_compute = (c & 4) ? 1u : 0xffffffffu;
+                tn.rows_r = (c & 8) ? 8u : 4u;
+                tn.walk_waves = (c & 16) ? 3u : 5u;
+                tn.walk_rows = 1u + (uint32_t)(c % 4);
+            } else if (c % 3 == 2) {
+                tn.rows_compute = 3000u;
+                tn.walk_waves = (c & 4) ? 2u : 8u;
+                tn.walk_compute = (c & 8) ? 0 : 1;
+            }
+            dpx::finalize(plan, tile, choice, tn);
             if (plan.error) { fprintf(stderr, "case %d: %s\n", c, plan.error); return 1; }
             std::vector<uint32_t> got(plan.n_samples + 1, 0);
             std::vector<uint8_t> writes(plan.n_samples + 1, 0);
