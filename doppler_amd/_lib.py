@@ -37,7 +37,7 @@ class Layout(C.Structure):
 class Options(C.Structure):
     _fields_ = [("rows_mult", C.c_uint32), ("rows_maxl", C.c_uint32), ("rows_r", C.c_uint32), ("walk_waves", C.c_uint32),
                 ("walk_rows", C.c_uint32), ("walk_compute", C.c_int32), ("walk_table_rows", C.c_uint32), ("rows_compute", C.c_uint32),
-                ("walk_tilemin", C.c_uint64)]
+                ("walk_tilemin", C.c_uint64), ("walk_span", C.c_uint32), ("walk_flags", C.c_uint32)]
 
 
 def make_options(opts):

@@ -141,6 +141,8 @@ dpx::PlanTuning tuning_of(const dpx_options *o)
     t.walk_compute = o->walk_compute;
     t.walk_table_rows = o->walk_table_rows;
     t.walk_tilemin = o->walk_tilemin;
+    t.walk_span = o->walk_span;
+    t.walk_flags = o->walk_flags;
     return t;
 }
 
@@ -472,6 +474,7 @@ int dpx_set_options(dpx_ctx *ctx, const dpx_options *opt)
         const uint32_t ww = opt->walk_waves;
         if (ww != 0 && (ww < 2 || ww > 8 || ww == 7)) return fail(DPX_ERR_ARG, "walk_waves must be 2, 3, 4, 5, 6 or 8");
         if (opt->walk_rows > 4) return fail(DPX_ERR_ARG, "walk_rows must be 1..4");
+        if (opt->walk_span > 4096) return fail(DPX_ERR_ARG, "walk_span must be 0 (default), 1 (walk kernel) or 2..4096 rows");
     }
     ctx->tuning = tuning_of(opt);
     return DPX_OK;

@@ -852,6 +852,266 @@ __device__ __forceinline__ void leftover_block(const uint8_t *__restrict__ in, u
     }
 }
 
+// ---- span kernel (round 3): the same matrices, the same descriptors, the same slice — but a workgroup keeps its
+// column window for a whole SPAN of rows (up to WalkArgs::span, the whole matrix when it is shorter) instead of one
+// chunk of WAVES x 2, its wavefronts taking two rows per turn until the span is done.
+//
+// Why (profiles/r03_walk.md, SQ counters on the 600 s replay): the walk kernel is not short of HBM requests, it is short
+// of VALU issue slots.  30.7 vector instructions per sample against 12.6 for the rows kernel, the vector ALUs 79 % busy,
+// and the shader clock down to 1.85 GHz under the 1400 W cap; half of those instructions are the slice — five wavefront
+// rounds of the bit-exact sincos per workgroup, shared by the 5-8 rows a one-second matrix gives a chunk.  What the
+// "fixed cost per workgroup" of round 2 measured was this arithmetic.  A span evaluates a slice once per 256 columns of
+// up to `span` rows: 75 / rows instructions per sample instead of 75 / 6.4, and every row of a matrix — the ninth of nine
+// as well — finds a wavefront of an already running workgroup.
+//
+// Shape of the row loop: the first two rows' loads are issued before the slice is evaluated (as in the walk kernel);
+// after the barrier each wavefront is on its own: mix and store the rows it holds, request the next two (rows
+// r + WAVES * 2), and so on — no further barrier, wavefronts of a span end independently.  Per row everything but the
+// lane's column offset is uniform and lives in scalar registers (row origin, shift, length); a window that lies wholly
+// inside a row (all but the last window of a matrix, and the rows a stretch end cuts) takes loads and stores without
+// any per-lane test.  Every wavefront of the workgroup takes part in the slice and reaches the barrier (the walk
+// kernel lets wavefronts without rows end before it).
+struct RowGeo {
+    uint64_t row0;      // first sample of the row's storage: the 32-sample boundary at or below A + r * L
+    uint32_t rowlen;    // samples from row0 to the next row's boundary (or the end of the matrix)
+    uint32_t off;       // slice entry of the row's column 0: kWalkPad - shift
+};
+
+__device__ __forceinline__ RowGeo row_geo(const WalkSeg &ws, uint32_t r)
+{
+    const uint64_t ideal = ws.A + (uint64_t)r * ws.L;
+    const uint64_t nxt = (ideal + ws.L) & ~31ull;
+    RowGeo g;
+    g.row0 = ideal & ~31ull;
+    g.rowlen = (uint32_t)((nxt < ws.E ? nxt : ws.E) - g.row0);
+    g.off = kWalkPad - ((uint32_t)ideal & 31u);
+    return g;
+}
+
+constexpr int kSpanU = 2;     // rows a wavefront takes per turn
+
+template <int IN_FMT, int OUT_FMT>
+struct SpanTypes {
+    typedef WalkVec<IN_FMT, OUT_FMT> WV;
+    static constexpr int S = WV::S;
+    static constexpr int NV = (int)WV::kCols / (kRowsLanes * S);
+    static constexpr int QW = S * Fmt<IN_FMT>::kBytes / 4;
+    typedef uint32_t qvec __attribute__((ext_vector_type(QW)));
+};
+
+// request one row's vectors; FULL: the window lies inside the row
+template <int IN_FMT, int OUT_FMT, bool FULL>
+__device__ __forceinline__ void span_load_row(const uint8_t *__restrict__ in, const RowGeo &g, uint32_t col0, uint32_t lane,
+                                              typename SpanTypes<IN_FMT, OUT_FMT>::qvec (&q)[SpanTypes<IN_FMT, OUT_FMT>::NV])
+{
+    typedef SpanTypes<IN_FMT, OUT_FMT> T;
+    constexpr int IB = Fmt<IN_FMT>::kBytes;
+    const uint8_t *rowp = in + g.row0 * IB;                       // uniform
+#pragma unroll
+    for (int v = 0; v < T::NV; ++v) {
+        uint32_t c = col0 + lane * T::S + (uint32_t)v * (kRowsLanes * T::S);
+        if constexpr (!FULL) c = c < g.rowlen ? c : 0u;           // a lane past the row reads the row's first vector instead
+        q[v] = __builtin_nontemporal_load(reinterpret_cast<const typename T::qvec *>(rowp + c * IB));
+    }
+}
+
+// mix one row with the slice and store it
+template <int IN_FMT, int OUT_FMT, bool FULL>
+__device__ __forceinline__ void span_finish_row(uint8_t *__restrict__ out, const RowGeo &g, uint32_t col0, uint32_t lane,
+                                                const typename SpanTypes<IN_FMT, OUT_FMT>::qvec (&q)[SpanTypes<IN_FMT, OUT_FMT>::NV],
+                                                const float2 *slice, uint32_t *xrow)
+{
+    typedef SpanTypes<IN_FMT, OUT_FMT> T;
+    constexpr int S = T::S, NV = T::NV;
+    constexpr int OB = Fmt<OUT_FMT>::kBytes;
+    constexpr bool XP = T::WV::kTranspose;
+    constexpr bool RAW = kRawI16<IN_FMT, OUT_FMT>;
+    typedef SlicePlanes<S, T::WV::kEntries> SP;
+    uint8_t *rowo = out + g.row0 * OB;                             // uniform
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const uint32_t c = col0 + lane * S + (uint32_t)v * (kRowsLanes * S);
+        float re[S], im[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const uint32_t ok = g.off + (uint32_t)k;              // uniform: plane and base position of corrector k
+            const float2 cs = slice[(ok & (SP::kPlanes - 1)) * SP::kStride + (ok >> SP::kLog2) + (uint32_t)v * kRowsLanes + lane];
+            float a, bq;
+            if constexpr (IN_FMT == DPX_FMT_I16) unpack_i16<RAW>(q[v][k], a, bq);
+            else { a = __uint_as_float(q[v][2 * k]); bq = __uint_as_float(q[v][2 * k + 1]); }
+            mix(a, bq, cs.x, cs.y, re[k], im[k]);
+        }
+        const bool active = FULL || c < g.rowlen;
+        if constexpr (OUT_FMT == DPX_FMT_I16) {
+            if constexpr (S == 4) {
+                u32x4 o = {pack_i16<RAW>(re[0], im[0]), pack_i16<RAW>(re[1], im[1]), pack_i16<RAW>(re[2], im[2]), pack_i16<RAW>(re[3], im[3])};
+                asm volatile("" : "+v"(o));   // keeps the vectoriser from rebuilding the store without its nt flag
+                if (active) __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(rowo + c * OB));
+            } else if constexpr (XP) {
+                u32x2 o;
+                o[0] = pack_i16<RAW>(re[0], im[0]);
+                o[1] = pack_i16<RAW>(re[1], im[1]);
+                *reinterpret_cast<u32x2 *>(xrow + (uint32_t)v * (kRowsLanes * S) + lane * S) = o;
+            } else {
+                u32x2 o;
+                o[0] = pack_i16<RAW>(re[0], im[0]);
+                o[1] = pack_i16<RAW>(re[1], im[1]);
+                if (active) __builtin_nontemporal_store(o, reinterpret_cast<u32x2 *>(rowo + c * OB));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < S / 2; ++i) {
+                u32x4 o;
+                o[0] = __float_as_uint(re[2 * i]);     o[1] = __float_as_uint(im[2 * i]);
+                o[2] = __float_as_uint(re[2 * i + 1]); o[3] = __float_as_uint(im[2 * i + 1]);
+                if (active) __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(rowo + c * OB) + i);
+            }
+        }
+    }
+    if constexpr (XP) {
+        // f32 -> i16: the row's 256 packed samples are in LDS (same wavefront: LDS operations execute in order) and
+        // leave as one 16-byte store per lane
+        __builtin_amdgcn_wave_barrier();
+        u32x4 o = *reinterpret_cast<const u32x4 *>(xrow + lane * 4);
+        asm volatile("" : "+v"(o));
+        const uint32_t c4 = col0 + lane * 4;
+        if (FULL || c4 < g.rowlen) __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(rowo + c4 * OB));
+    }
+}
+
+template <int IN_FMT, int OUT_FMT, bool FMA, int WAVES>
+__device__ __forceinline__ void span_body(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const WalkSeg &ws,
+                                          uint32_t w, uint32_t half, uint32_t wave, uint32_t lane, uint32_t tid,
+                                          float2 *slice, uint32_t *xpose)
+{
+    typedef SpanTypes<IN_FMT, OUT_FMT> T;
+    typedef typename T::WV WV;
+    constexpr int U = kSpanU, NV = T::NV;
+    constexpr int THREADS = WAVES * 64;
+    constexpr uint32_t kEntries = WV::kEntries;                  // 288, or 160 for half a window
+    typedef SlicePlanes<T::S, kEntries> SP;
+    const uint32_t col0 = w * kWalkWindow + half * WV::kCols;    // first column of this workgroup
+    const uint32_t stride = WAVES * U;
+
+    uint32_t r = ws.row0 + wave * U;                             // this wavefront's rows: r, r + 1, then r + stride ...
+    typename T::qvec q[U][NV];
+    auto request = [&](uint32_t rr) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (rr + u < ws.row_end) {                           // uniform
+                const RowGeo g = row_geo(ws, rr + u);
+#ifndef DPX_EXP_NOCONT
+                if (col0 >= g.rowlen) continue;                  // the matrix's last row ends before this window
+#endif
+                if (col0 + WV::kCols <= g.rowlen) span_load_row<IN_FMT, OUT_FMT, true>(in, g, col0, lane, q[u]);
+                else                              span_load_row<IN_FMT, OUT_FMT, false>(in, g, col0, lane, q[u]);
+            }
+        }
+    };
+    request(r);
+
+    // the slice: thread j evaluates entry j (the first 32 threads also entry 256 + j) with the bit-exact sincos, after the
+    // first rows' loads have been issued; entry j = corrector of column col0 + j - kWalkPad
+    {
+        const uint32_t P = ws.period;
+        // counter of entry j, minus one: (phase + col0 + j - kWalkPad) mod P.  The part that does not depend on j is
+        // reduced once (uniform; rows are multiples of the period, so col0 may exceed it many times), entry by entry
+        // one conditional subtraction is left — periods shorter than a slice take the modulo per entry.
+        const uint32_t ub = (ws.phase + col0 + P * kWalkPad - kWalkPad) % P;     // 32-bit: phase < P, col0 <= L, P <= 2^22 (kLutMaxEntries)
+        constexpr int kRounds = ((int)kEntries + THREADS - 1) / THREADS;
+#pragma unroll
+        for (int it = 0; it < kRounds; ++it) {
+            const uint32_t j = tid + (uint32_t)it * THREADS;
+            if (j < kEntries) {
+                uint32_t t = ub + j;
+#ifdef DPX_EXP_OLDMOD
+                if (ws.L == P) {
+                    t = ws.phase + col0 + j + P - kWalkPad;
+                    t = t >= 2u * P ? t - 2u * P : t;
+                    t = t >= P ? t - P : t;
+                    t = t >= P ? t - P : t;
+                } else
+#endif
+                if (P > kEntries) t = t >= P ? t - P : t;        // uniform: j < kEntries < P
+                else              t %= P;
+                float c, sn;
+                corrector<FMA>(ws.ratio, t + 1u, c, sn);
+                slice[SP::index(j)] = make_float2(c, sn);
+            }
+        }
+    }
+    __syncthreads();
+
+    while (r < ws.row_end) {                                     // uniform per wavefront
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r + u < ws.row_end) {
+                const RowGeo g = row_geo(ws, r + u);
+#ifndef DPX_EXP_NOCONT
+                if (col0 >= g.rowlen) continue;
+#endif
+                uint32_t *xrow = xpose + (wave * U + u) * kWalkWindow;
+                if (col0 + WV::kCols <= g.rowlen) span_finish_row<IN_FMT, OUT_FMT, true>(out, g, col0, lane, q[u], slice, xrow);
+                else                              span_finish_row<IN_FMT, OUT_FMT, false>(out, g, col0, lane, q[u], slice, xrow);
+            }
+        }
+        r += stride;
+        request(r);
+    }
+}
+
+// UNI: a launch of ONE matrix (WalkUni): the matrix comes with the kernel arguments, the span is blockIdx.y, the window
+// blockIdx.x; grid rows past the last span hold the leftover blocks (head and tail of the stretch).
+template <int IN_FMT, int OUT_FMT, bool FMA, int WAVES, bool UNI>
+__global__ __launch_bounds__(WAVES * 64) void span_kernel(const uint8_t *__restrict__ in,
+                                                            uint8_t *__restrict__ out,
+                                                            WalkUni uni,                           // UNI only
+                                                            const WalkSeg *__restrict__ wdesc,     // !UNI only
+                                                            uint32_t n_left_wg,
+                                                            // ---- leftover path only
+                                                            const LeftRange *__restrict__ left,
+                                                            const uint32_t *__restrict__ lhint,
+                                                            const DevSeg *__restrict__ segs)
+{
+    constexpr int S = WalkVec<IN_FMT, OUT_FMT>::S;
+    constexpr int THREADS = WAVES * 64;
+    constexpr bool XP = WalkVec<IN_FMT, OUT_FMT>::kTranspose;
+    typedef SlicePlanes<S, WalkVec<IN_FMT, OUT_FMT>::kEntries> SPK;
+    __shared__ float2 slice[SPK::kPlanes * SPK::kStride];
+    __shared__ uint32_t xpose[XP ? WAVES * kSpanU * (int)kWalkWindow : 1];   // packed i16 samples of one row per (wavefront, u)
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t kSplit = WalkVec<IN_FMT, OUT_FMT>::kSplit;
+    const uint32_t half = blockIdx.x % kSplit;
+    if constexpr (UNI) {
+        const uint32_t w = blockIdx.x / kSplit, c = blockIdx.y;
+        if (c < uni.n_spans) {
+            if (w >= uni.seg.nw) return;                          // padding
+            WalkSeg ws = uni.seg;
+            ws.row0 = c * uni.base + (c < uni.rem ? c : uni.rem);
+            ws.row_end = ws.row0 + uni.base + (c < uni.rem ? 1u : 0u);
+            const uint32_t lane = tid & (kRowsLanes - 1), wave = __builtin_amdgcn_readfirstlane(tid / kRowsLanes);
+            span_body<IN_FMT, OUT_FMT, FMA, WAVES>(in, out, ws, w, half, wave, lane, tid, slice, xpose);
+        } else {
+            const uint32_t e = (c - uni.n_spans) * uni.nw8 + w;   // leftover block
+            if (half != 0 || e >= n_left_wg) return;
+            leftover_block<IN_FMT, OUT_FMT, FMA, THREADS>(in, out, left, lhint, segs, e, tid);
+        }
+    } else {
+        // the descriptor of this group of 8 workgroups (as in the walk kernel): a span of a matrix, or a group of leftover blocks
+        const uint32_t b = blockIdx.x / kSplit;
+        const WalkSeg ws = wdesc[b >> kWalkHintShift];
+        const uint32_t w = b - ws.wg_base;
+        if (w >= ws.nw) return;                                   // padding
+        if (ws.upw != 0) {
+            const uint32_t lane = tid & (kRowsLanes - 1), wave = __builtin_amdgcn_readfirstlane(tid / kRowsLanes);
+            span_body<IN_FMT, OUT_FMT, FMA, WAVES>(in, out, ws, w, half, wave, lane, tid, slice, xpose);
+        } else {
+            if (half != 0) return;                                // a leftover block is one workgroup whatever the grid scaling
+            leftover_block<IN_FMT, OUT_FMT, FMA, THREADS>(in, out, left, lhint, segs, ws.row0 + w, tid);
+        }
+    }
+}
+
 // plan-time: entry e of a table = corrector(((n_first - 1 + e) mod period) + 1)
 template <bool FMA>
 __global__ __launch_bounds__(256) void build_lut_kernel(float2 *__restrict__ tab, uint32_t period,
@@ -1015,6 +1275,28 @@ static int walk_t(const void *d_in, void *d_out, const DevSeg *d_segs, const voi
     if (n_wg == 0) return DPX_OK;
     if (n_wg > 0x7fffffffull) return DPX_ERR_ARG;
     const dim3 grid((uint32_t)n_wg);
+    if (w.span != 0) {
+        constexpr uint32_t kSplit = WalkVec<IN_FMT, OUT_FMT>::kSplit;
+        const bool uni = w.uni.n_spans != 0;
+        // one matrix: windows along x, spans along y, then the rows of the grid that hold the leftover blocks
+        const uint32_t left_rows = uni ? (w.n_left_wg + w.uni.nw8 - 1) / w.uni.nw8 : 0;
+        const dim3 ugrid(uni ? w.uni.nw8 * kSplit : 1, uni ? w.uni.n_spans + left_rows : 1);
+        if (uni && ugrid.y > 65535u) return DPX_ERR_ARG;
+#define DPX_SPAN_CASE(WW)                                                                                                              \
+        if (w.waves == WW) {                                                                                                           \
+            if (uni) {                                                                                                                 \
+                if (fma) span_kernel<IN_FMT, OUT_FMT, true, WW, true><<<ugrid, WW * 64, 0, st>>>(in, out, w.uni, d_wdesc, w.n_left_wg, d_left, d_lhint, d_segs);   \
+                else     span_kernel<IN_FMT, OUT_FMT, false, WW, true><<<ugrid, WW * 64, 0, st>>>(in, out, w.uni, d_wdesc, w.n_left_wg, d_left, d_lhint, d_segs);  \
+            } else {                                                                                                                   \
+                if (fma) span_kernel<IN_FMT, OUT_FMT, true, WW, false><<<grid, WW * 64, 0, st>>>(in, out, w.uni, d_wdesc, w.n_left_wg, d_left, d_lhint, d_segs);   \
+                else     span_kernel<IN_FMT, OUT_FMT, false, WW, false><<<grid, WW * 64, 0, st>>>(in, out, w.uni, d_wdesc, w.n_left_wg, d_left, d_lhint, d_segs);  \
+            }                                                                                                                          \
+            return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                                             \
+        }
+        DPX_SPAN_CASE(4) DPX_SPAN_CASE(5) DPX_SPAN_CASE(8) DPX_SPAN_CASE(2)
+#undef DPX_SPAN_CASE
+        return DPX_ERR_ARG;
+    }
 #define DPX_WALK_CASE(WW)                                                                                                              \
     if (w.waves == WW) {                                                                                                               \
         if (fma) walk_kernel<IN_FMT, OUT_FMT, true, WW><<<grid, WW * 64, 0, st>>>(in, out, lut, d_wdesc, w.n_left_wg, sink, d_left, d_lhint, d_segs);  \

@@ -326,24 +326,41 @@ constexpr uint32_t kWalkTableRows = 0xffffffffu;   // never: evaluating the slic
 constexpr uint64_t kWalkTileMinDefault = 1ull << 22;   // an uncovered gap at least this long gets its own tile launch ...
 constexpr size_t kWalkMaxTileLaunches = 8;       // ... up to this many; the rest is evaluated by leftover workgroups
 
-struct WalkShape { uint32_t waves, rows_per_wave; };
+struct WalkShape { uint32_t waves, rows_per_wave, span; };
+// span != 0: the span kernel (a workgroup keeps its window for up to `span` rows, two per wavefront per turn);
+// span == 0: the walk kernel (chunks of waves x rows_per_wave rows).  Plans that ask for tables are walk plans.
 WalkShape walk_shape(const PlanTuning &tn)
 {
-    WalkShape g = {kWalkWaves, kWalkRowsPerWave};
+    WalkShape g = {kWalkWaves, kWalkRowsPerWave, 0};
     if (tn.walk_waves) g.waves = tn.walk_waves;                                // measurement overrides
     if (tn.walk_rows) g.rows_per_wave = std::min(tn.walk_rows, kWalkMaxRowsPerWave);
+    const bool tables = tn.walk_compute == 0 || (tn.walk_compute < 0 && tn.walk_table_rows != 0);
+    if (tn.walk_span != 1 && !tables) {
+        g.span = tn.walk_span ? tn.walk_span : kSpanRows;
+        g.rows_per_wave = 2;
+        if (!(g.waves == 2 || g.waves == 4 || g.waves == 5 || g.waves == 8)) g.waves = kSpanWaves;
+    }
     return g;
 }
 
 // matrix of the walk kernel for one stretch (dpx_types.h, WalkSeg); false if the stretch does not qualify
-bool walk_geometry(const DevSeg &s, WalkSeg *w)
+bool walk_geometry(const DevSeg &s, WalkSeg *w, const PlanTuning &tn)
 {
     if (s.lut_len == 0 || s.period == 0) return false;
     const uint64_t end = s.first + s.count;
     const uint64_t A = (s.first + 31) & ~31ull, E = end & ~31ull;
     if (E <= A) return false;
     const uint64_t P = s.period;
-    const uint64_t L = P >= kWalkMinL ? P : P * ((kWalkMinL + P - 1) / P);
+    // Row length: a multiple of the period.  Measured (profiles/r03_walk.md, `tools/ab.py --set minl`, replay classes): rows
+    // of 0.5-1 MB (128-256 Ki samples) run 1-4 points faster than rows of one period of 10-100 thousand samples (fewer, longer
+    // fronts in flight), so a long stretch takes the multiple that reaches kWalkRowTarget; a short one (a second of stream)
+    // stops where its rows still fill one span of 8, and keeps the period itself while that gives no more than 12 rows.
+    const uint64_t target = (tn.walk_flags >> 8) ? (uint64_t)(tn.walk_flags >> 8) * 1024u : kWalkRowTarget;   // measurement: bits 8.. of walk_flags
+    const uint64_t r = (E - A) / P;
+    uint64_t m = 1;
+    if (r > 12) m = std::min((target + P - 1) / P, (r + 7) / 8);
+    if (P * m < kWalkMinL) m = (kWalkMinL + P - 1) / P;
+    const uint64_t L = P * m;
     if (L > kLutMaxEntries || E - A < 2 * L) return false;     // the table must be reused at least once
     const uint64_t rows = (E - A + L - 1) / L;
     const uint64_t longest = (L % 32 == 0) ? L : (L & ~31ull) + 32;   // rows start on 32-sample boundaries
@@ -368,7 +385,12 @@ bool walk_geometry(const DevSeg &s, WalkSeg *w)
 
 uint32_t walk_chunks(const WalkSeg &w, const PlanTuning &tn)
 {
-    const uint32_t rpw = walk_shape(tn).waves * walk_shape(tn).rows_per_wave;
+    const WalkShape g = walk_shape(tn);
+    // span kernel: a matrix of up to kSpanWhole rows (every one-second matrix under the row-length rule above) is ONE span — its
+    // slice is evaluated once, the rows past the first 8 take a second turn (replay 76.3 -> 78.0 % against spans of 8, measured);
+    // a taller matrix is cut into spans of 8 = one turn each (const mode: 80.1 % with 8, 79.2 with 12, 77.5 with 16)
+    if (g.span && !tn.walk_span && w.rows <= kSpanWhole) return 1;
+    const uint32_t rpw = g.span ? g.span : g.waves * g.rows_per_wave;
     return (uint32_t)(((uint64_t)w.rows + rpw - 1) / rpw);
 }
 
@@ -435,7 +457,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         uint64_t in_matrices = 0, n_wg = 0;
         for (const DevSeg &s : plan.segs) {
             WalkSeg w;
-            if (!walk_geometry(s, &w)) continue;
+            if (!walk_geometry(s, &w, tn)) continue;
             in_matrices += w.E - w.A;
             n_wg += walk_workgroups(w, tn);
         }
@@ -448,7 +470,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
     // the long matrices of const-mode plans (measured, profiles/r02_walk.md: replay 74.8 / 72.4 % with 4 / 5 wavefronts,
     // const 5001 Hz 78.8 / 80.0 %).
     PlanTuning tnw = tn;
-    if (!tnw.walk_waves) tnw.walk_waves = use_walk ? kWalkWavesTrack : kWalkWaves;
+    if (!tnw.walk_waves) tnw.walk_waves = walk_shape(tn).span ? kSpanWaves : use_walk ? kWalkWavesTrack : kWalkWaves;
 
     // Const-mode plans: a stretch whose period does not allow rows of whole 4 KiB pages (odd periods: the common case
     // for an arbitrary integer --shift) runs 4-23 % faster as a walk-kernel matrix than as a rows launch with
@@ -461,7 +483,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
             uint32_t R, L;
             WalkSeg w;
             const bool page_rows = rows_geometry(plan.segs[i], &A, &R, &L) && L % 1024 == 0;
-            if (!page_rows && walk_geometry(plan.segs[i], &w)) {
+            if (!page_rows && walk_geometry(plan.segs[i], &w, tn)) {
                 to_walk[i] = 1;
                 plan.segs[i].flags |= kSegWalk;
             }
@@ -555,7 +577,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
             DevSeg &s = plan.segs[i];
             const uint64_t end = s.first + s.count;
             WalkSeg w;
-            if (!(use_walk || to_walk[i]) || !walk_geometry(s, &w)) {
+            if (!(use_walk || to_walk[i]) || !walk_geometry(s, &w, tn)) {
                 s.flags &= ~kSegWalk;
                 uncovered(s.first, end, (uint32_t)i);
                 continue;
@@ -606,7 +628,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         // The leftover workgroups (sincos per sample: VALU-bound) are dealt out in groups of 8 between the chunks, evenly
         // over the grid, so that their arithmetic runs beside memory-bound matrix workgroups on every CU instead of in a
         // block of its own (all at the front: 5-8 % of the 600-second replay for 1 % of its samples; at the end: worse).
-        const uint32_t waves = walk_shape(tnw).waves, max_upw = walk_shape(tnw).rows_per_wave;
+        const uint32_t waves = walk_shape(tnw).waves, max_upw = walk_shape(tnw).rows_per_wave, span = walk_shape(tnw).span;
         uint64_t m_groups = 0;
         for (const WalkSeg &m : mats) m_groups += (uint64_t)((m.nw + 7) / 8) * walk_chunks(m, tnw);
         const uint64_t l_groups = (left_wg + 7) / 8;
@@ -631,7 +653,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
                 const uint32_t h = base + (c < rem ? 1u : 0u);
                 w.row0 = c * base + std::min(c, rem);
                 w.row_end = w.row0 + h;
-                w.upw = std::max(std::min(2u, max_upw), (h + waves - 1) / waves);
+                w.upw = span ? 2u : std::max(std::min(2u, max_upw), (h + waves - 1) / waves);
                 w.wg_base = (uint32_t)wg;
                 wg += (w.nw + 7) & ~7u;
                 plan.walk.push_back(w);
@@ -649,7 +671,20 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         ln.walk.waves = walk_shape(tnw).waves;
         ln.walk.rows_per_wave = walk_shape(tnw).rows_per_wave;
         ln.walk.compute_slice = 0;
+        ln.walk.span = span;
+        memset(&ln.walk.uni, 0, sizeof ln.walk.uni);
+        if (span && mats.size() == 1 && !(tn.walk_flags & 1u)) {      // one matrix: the kernel takes it from its arguments
+            const uint32_t k = walk_chunks(mats[0], tnw);
+            ln.walk.uni.seg = mats[0];
+            ln.walk.uni.seg.upw = 2;
+            ln.walk.uni.n_spans = k;
+            ln.walk.uni.base = mats[0].rows / k;
+            ln.walk.uni.rem = mats[0].rows % k;
+            ln.walk.uni.nw8 = (mats[0].nw + 7) & ~7u;
+            if ((uint64_t)k + (left_wg + ln.walk.uni.nw8 - 1) / ln.walk.uni.nw8 > 65535u) ln.walk.uni.n_spans = 0;   // grid rows
+        }
         for (const WalkSeg &m : mats) if (m.tab_off == kWalkNoTable) ln.walk.compute_slice = 1;
+        for (const WalkSeg &m : mats) if (span && m.tab_off != kWalkNoTable) plan.error = "span launches evaluate every slice";
         plan.launches.push_back(ln);
         // sentinels end the kernels' forward scans; hints give the scan its starting point
         WalkSeg wend;
@@ -772,6 +807,21 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
             for (uint64_t g = r.B; g < r.r1; ++g) generic(r.seg_lo, g);
         } else if (ln.kind == 2) {
             const WalkArgs &wa = ln.walk;
+            if (wa.uni.n_spans) {
+                // a one-matrix launch takes the spans from its arguments: they must be the descriptor list's spans
+                uint32_t c = 0;
+                for (size_t i = 0; i + 1 < plan.walk.size(); ++i) {
+                    const WalkSeg &d = plan.walk[i];
+                    if (d.upw == 0) continue;
+                    const WalkUni &u = wa.uni;
+                    const uint32_t row0 = c * u.base + std::min(c, u.rem), row_end = row0 + u.base + (c < u.rem ? 1u : 0u);
+                    if (d.A != u.seg.A || d.E != u.seg.E || d.L != u.seg.L || d.nw != u.seg.nw || d.period != u.seg.period || d.phase != u.seg.phase ||
+                        memcmp(&d.ratio, &u.seg.ratio, 4) != 0 || d.row0 != row0 || d.row_end != row_end || d.tab_off != kWalkNoTable ||
+                        u.nw8 != ((d.nw + 7u) & ~7u)) put(0, 0xfffffff8u);
+                    ++c;
+                }
+                if (c != wa.uni.n_spans) put(0, 0xfffffff7u);
+            }
             for (uint32_t b = 0; b < wa.n_walk_wg; ++b) {
                 const WalkSeg &ws = plan.walk[plan.walk_hint[b >> kWalkHintShift]];
                 if (b < ws.wg_base || b - ws.wg_base >= ((ws.nw + 7u) & ~7u)) { put(0, 0xfffffffcu); continue; }   // hint not exact
@@ -793,7 +843,8 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
                 }
                 const TableBuild *tb = nullptr;
                 for (const TableBuild &t : plan.tables) if (t.off == ws.tab_off) tb = &t;
-                if (ws.upw < 1 || ws.upw > wa.rows_per_wave || ws.row_end > ws.rows || ws.row_end - ws.row0 > wa.waves * ws.upw) { put(0, 0xfffffffbu); continue; }
+                if (ws.upw < 1 || ws.upw > wa.rows_per_wave || ws.row_end > ws.rows || ws.row_end <= ws.row0 ||
+                    ws.row_end - ws.row0 > (wa.span ? std::max(wa.span, kSpanWhole) : wa.waves * ws.upw) || (wa.span && ws.tab_off != kWalkNoTable)) { put(0, 0xfffffffbu); continue; }
                 for (uint32_t r = ws.row0; r < ws.row_end; ++r) {
                     const uint64_t ideal = ws.A + (uint64_t)r * ws.L;
                     const uint64_t row0 = ideal & ~31ull;
@@ -809,7 +860,14 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
                             const uint32_t P = ws.period;
                             const uint32_t ub = ws.phase + w * kWalkWindow;
                             uint32_t t;
-                            if (ws.L == P) {
+                            if (wa.span) {                                        // span kernel: one reduction per workgroup, then one subtraction
+                                if ((uint64_t)ws.phase + (uint64_t)(w + 1) * kWalkWindow + (uint64_t)P * kWalkPad > 0xffffffffull) { put(row0 + c, 0xfffffff6u); continue; }
+                                const uint32_t ub2 = (ws.phase + w * kWalkWindow + P * kWalkPad - kWalkPad) % P;              // the kernel's 32-bit arithmetic
+                                t = ub2 + j;
+                                if (P > kWalkSlice) t = t >= P ? t - P : t;
+                                else                t %= P;
+                                if (t >= P) { put(row0 + c, 0xfffffffdu); continue; }
+                            } else if (ws.L == P) {
                                 t = ub + j + P - kWalkPad;
                                 t = t >= 2u * P ? t - 2u * P : t;
                                 t = t >= P ? t - P : t;

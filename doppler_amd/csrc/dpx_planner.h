@@ -61,6 +61,10 @@ struct PlanTuning {
     int walk_compute = -1;       // walk kernel: 1 = workgroups always evaluate their corrector slices, 0 = always read
                                  // plan-time tables, -1 = per matrix: tables from walk_table_rows rows on
     uint32_t walk_table_rows = 0;  // that threshold (0 = the planner's default)
+    uint32_t walk_span = 0;      // span kernel: most rows per span (0 = the planner's default, kSpanRows); 1 = the walk kernel's
+                                 // chunks of waves x rows instead (round 2's shape; also taken whenever a matrix gets a table)
+    uint32_t walk_flags = 0;     // bit 0: a one-matrix span launch reads descriptors like any other (measurement of what the
+                                 // descriptor load costs)
 };
 
 struct PlanResult {

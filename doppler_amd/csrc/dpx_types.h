@@ -132,7 +132,8 @@ static_assert(sizeof(LeftRange) == 24, "LeftRange is read with scalar loads");
 constexpr uint32_t kWalkNoTable = 0xffffffffu;
 constexpr uint32_t kWalkPad = 32;          // table entries before column 0 (the largest row shift is 31)
 constexpr uint32_t kWalkWindow = 256;      // samples per column window
-constexpr uint32_t kWalkMinL = 8192;       // shorter periods use a multiple as the row length
+constexpr uint32_t kWalkMinL = 8192;       // no row is shorter (a multiple of the period otherwise)
+constexpr uint32_t kWalkRowTarget = 262144; // long matrices: the multiple of the period that reaches this many samples (1 MB of i16) per row
 constexpr int kWalkHintShift = 3;          // one WalkSeg index per 8 workgroups: exact, every chunk is padded to a multiple of 8
 constexpr int kLeftHintShift = 4;          // one LeftRange hint per 16 leftover workgroups
 constexpr uint32_t kLeftBlock = 1024;      // samples per leftover workgroup
@@ -141,7 +142,22 @@ constexpr uint32_t kWalkWavesTrack = 4;
 constexpr uint32_t kWalkRowsPerWave = 2;   // ... and the most rows a wavefront takes by default (measured best; the kernel handles 1..4 per chunk)
 constexpr uint32_t kWalkMaxRowsPerWave = 4;
 constexpr uint32_t kWalkSlice = kWalkWindow + kWalkPad;   // table entries a window needs: 288
+constexpr uint32_t kSpanRows = 8;          // span kernel: most rows of a matrix one workgroup keeps its window for (dpx_options.walk_span): one turn of 4 x 2
+constexpr uint32_t kSpanWhole = 12;        // ... but a matrix of up to this many rows is one span
+constexpr uint32_t kSpanWaves = 4;         // span kernel: wavefronts per workgroup
 constexpr uint32_t kWalkSinkBytes = 512 * 16;             // where lanes without a sample store
+
+// A walk launch that consists of ONE matrix (const mode: an odd period, or a long one) needs no descriptor table at all:
+// every span is the same WalkSeg but for its rows, which follow from the span's index.  The span kernel then takes the
+// matrix from its kernel arguments (the first dwords preloaded into scalar registers at wavefront launch) and the span
+// from blockIdx.y, and issues its sample loads without the scalar-load round trip that every workgroup of a
+// many-matrix launch starts with (to HBM: each group of 8 workgroups has its own descriptor line).
+struct WalkUni {
+    WalkSeg seg;           // the matrix; row0 / row_end / wg_base unused
+    uint32_t n_spans;      // 0: not a one-matrix launch
+    uint32_t base, rem;    // span c takes rows [c * base + min(c, rem), + base + (c < rem))
+    uint32_t nw8;          // workgroups per span in the descriptor list: nw rounded up to a multiple of 8
+};
 
 struct WalkArgs {
     uint32_t n_walk_wg;    // workgroups walking matrices
@@ -149,6 +165,9 @@ struct WalkArgs {
     uint32_t n_segs;
     uint32_t waves, rows_per_wave;   // workgroup geometry the descriptors were laid out for (rows_per_wave: the most a chunk may ask for)
     uint32_t compute_slice;          // informational: 1 if any chunk evaluates its slices itself (WalkSeg::tab_off == kWalkNoTable)
+    uint32_t span;                   // != 0: span kernel — a descriptor is a span of up to this many rows, its workgroups loop over them
+                                     // two rows per wavefront per turn (every slice evaluated); 0: walk kernel, chunks of waves x rows_per_wave
+    WalkUni uni;                     // span launches of one matrix
 };
 
 struct TileArgs {

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DPX_ABI_VERSION 2
+#define DPX_ABI_VERSION 3
 
 /* reference src/usage.rs:39-42  enum DataType { F32, I16 } */
 #define DPX_FMT_I16 0
@@ -128,6 +128,10 @@ typedef struct dpx_options {
                               * its wavefronts evaluate their columns' correctors (0 = the planner's threshold, 0xffffffff = never,
                               * 1 = always and for every format pair) */
     uint64_t walk_tilemin;   /* walk plans: uncovered gaps at least this long (samples) get a tile-kernel launch */
+    uint32_t walk_span;      /* span kernel (ABI 3): most rows of a matrix one workgroup keeps its column window for (0 = the planner's
+                              * default, 32); 1 = round 2's walk kernel instead (chunks of walk_waves x walk_rows rows) */
+    uint32_t walk_flags;     /* bit 0: a span launch of ONE matrix reads its descriptors from memory like a many-matrix launch instead
+                              * of taking the matrix from its kernel arguments */
 } dpx_options;
 /* applies to plans created afterwards; NULL restores the defaults */
 int dpx_set_options(dpx_ctx *ctx, const dpx_options *opt);

@@ -75,7 +75,10 @@ int main(int argc, char **argv)
                 tn.rows_r = (c & 8) ? 8u : 4u;
                 tn.walk_waves = (c & 16) ? 3u : 5u;
                 tn.walk_rows = 1u + (uint32_t)(c % 4);
+                tn.walk_span = (c & 32) ? 1u : 0u;                     // the walk kernel's chunks / the span kernel's default spans
             } else if (c % 3 == 2) {
+                tn.walk_span = (c & 16) ? 0u : 2u + (uint32_t)(c % 37);   // explicit span heights 2..38
+                tn.walk_flags = ((c & 32) ? 1u : 0u) | ((c & 64) ? (uint32_t)(8 + c % 300) << 8 : 0u);   // descriptors from memory; row-length target
                 tn.rows_compute = 3000u;
                 tn.walk_waves = (c & 4) ? 2u : 8u;
                 tn.walk_compute = (c & 8) ? 0 : 1;

@@ -395,7 +395,7 @@ def test_walk_kernel_workgroup_shapes_and_on_the_fly_slices(ctx, orc, waves, max
     # periods 8192..40000 at this rate: rows = count / period takes many residues modulo 2 * waves
     segs = [(rate + 2048 * k, float(np.float32(-3000.0 + 517.3 * k))) for k in range(9)] + [(5 * rate // 2, 1000.0), (3 * rate, 7.0)]
     n = sum(c for c, _ in segs)
-    opts = dict(walk_waves=waves, walk_rows=max_rows, walk_compute=compute)
+    opts = dict(walk_waves=waves, walk_rows=max_rows, walk_compute=compute, walk_span=1)     # walk_span=1: the walk kernel, not spans
     lay = doppler_amd.plan_layout(segs, rate, variant=5, options=opts)
     assert lay["walk_launches"] == 1 and lay["walk_matrices"] >= 9 and lay["rows_launches"] == 0, lay
     assert lay["table_entries"] == 0 or not compute
@@ -408,6 +408,62 @@ def test_walk_kernel_workgroup_shapes_and_on_the_fly_slices(ctx, orc, waves, max
             got, fin = run_bulk(ctx, x, intype, outtype, segs, rate)
             assert fin == sn
             assert_same_bytes(got, want, outtype, "walk %d waves x <=%d rows, compute=%d, %s->%s" % (waves, max_rows, compute, intype, outtype))
+    finally:
+        ctx.set_options()
+        ctx.set_tuning(0, 0, 3)
+
+
+@pytest.mark.parametrize("waves", [2, 4, 5, 8])
+@pytest.mark.parametrize("span", [0, 2, 3, 7, 9, 16, 33, 4096])
+def test_span_kernel_shapes(ctx, orc, waves, span):
+    """The span kernel (round 3: a workgroup keeps its column window for up to `span` rows of a matrix, two rows per
+    wavefront per turn): every workgroup size, spans from a single turn (2, 3 rows: wavefronts without rows still take
+    part in the slice and the barrier) to whole matrices (4096), heights that leave the last turn with one row or with
+    idle wavefronts, odd periods (every row shifted differently against the slice), all format pairs."""
+    import doppler_amd
+    rate = 256000
+    segs = [(rate + 2048 * k, float(np.float32(-3000.0 + 517.3 * k))) for k in range(9)] + [(5 * rate // 2, 1000.0), (3 * rate, 7.0), (rate // 3, 1234.5)]
+    n = sum(c for c, _ in segs)
+    opts = dict(walk_waves=waves, walk_span=span)
+    lay = doppler_amd.plan_layout(segs, rate, variant=5, options=opts)
+    assert lay["walk_launches"] == 1 and lay["walk_matrices"] >= 9 and lay["rows_launches"] == 0 and lay["table_entries"] == 0, lay
+    ctx.set_tuning(0, 0, 5)
+    ctx.set_options(**opts)
+    try:
+        for intype, outtype in (("i16", "i16"), ("f32", "i16"), ("i16", "f32"), ("f32", "f32")):
+            x = make_iq(intype, n, 1700 + waves, full_scale=True)
+            want, sn = orc.segments_stream(x, intype, outtype, segs, rate, threads=16)
+            got, fin = run_bulk(ctx, x, intype, outtype, segs, rate)
+            assert fin == sn
+            assert_same_bytes(got, want, outtype, "span kernel, %d waves, span %d, %s->%s" % (waves, span, intype, outtype))
+    finally:
+        ctx.set_options()
+        ctx.set_tuning(0, 0, 3)
+
+
+@pytest.mark.parametrize("span,flags", [(0, 0), (0, 1), (3, 0), (40, 0), (4096, 0)])
+def test_span_kernel_one_matrix_launch(ctx, orc, span, flags):
+    """Const mode on the span kernel: a launch of ONE matrix takes the matrix from its kernel arguments and the span from
+    blockIdx.y (walk_flags=1: from descriptors in memory, like a track-shaped plan); odd period, a period with rows of whole
+    lines, a counter carried in, head and tail as leftover blocks in the last grid rows; all format pairs."""
+    import doppler_amd
+    cases = [((5001.0, 1024000), 0), ((777.0, 1024000), 12345), ((100.0, 1024000), 7)]
+    n = (1 << 22) + 4321
+    opts = dict(walk_span=span, walk_flags=flags)
+    ctx.set_tuning(0, 0, 5)
+    ctx.set_options(**opts)
+    try:
+        for (shift, rate), sn0 in cases:
+            lay = doppler_amd.plan_layout([(n, shift)], rate, sn0, variant=5, options=opts)
+            assert lay["walk_launches"] == 1 and lay["walk_matrices"] == 1 and lay["rows_launches"] == 0, lay
+            for intype, outtype in (("i16", "i16"), ("f32", "i16"), ("i16", "f32"), ("f32", "f32")):
+                x = make_iq(intype, n, 5100 + sn0, full_scale=True)
+                cx = orc.convert_iqi16_to_complex(x) if intype == "i16" else orc.convert_iqf32_to_complex(x)
+                o, sn_w = orc.shift_frequency(cx, sn0, shift, rate)
+                want = orc.pack_i16(o) if outtype == "i16" else orc.pack_f32(o)
+                got, fin = run_bulk(ctx, x, intype, outtype, [(n, shift)], rate, sn0)
+                assert fin == sn_w
+                assert_same_bytes(got, want, outtype, "one-matrix span launch, span=%d flags=%d shift=%r %s->%s" % (span, flags, shift, intype, outtype))
     finally:
         ctx.set_options()
         ctx.set_tuning(0, 0, 3)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert set(declared) == set(_lib._SIGNATURES), set(declared) ^ set(_lib._SIGNATURES)
-    assert doppler_amd.lib.dpx_abi_version() == 2
+    assert doppler_amd.lib.dpx_abi_version() == 3
 
 
 def test_no_cpu_fallback_anywhere():
@@ -145,7 +145,9 @@ def test_walk_kernel_plans(orc):
             assert np.array_equal(c, want), (segs[:3], variant, np.flatnonzero(c != want)[:5])
         # the measurement knobs (dpx_options) change the launch shapes, never the counters
         for opts in (dict(walk_compute=1), dict(walk_compute=0), dict(walk_table_rows=3), dict(walk_waves=4), dict(walk_waves=8, walk_compute=1), dict(walk_waves=6, walk_tilemin=1000),
-                     dict(rows_r=4, rows_mult=3), dict(walk_rows=1), dict(walk_rows=2, walk_waves=4), dict(walk_waves=2), dict(walk_waves=3, walk_compute=0), dict(walk_rows=3, walk_compute=1)):
+                     dict(rows_r=4, rows_mult=3), dict(walk_rows=1), dict(walk_rows=2, walk_waves=4), dict(walk_waves=2), dict(walk_waves=3, walk_compute=0), dict(walk_rows=3, walk_compute=1),
+                     dict(walk_span=1), dict(walk_span=1, walk_compute=1, walk_waves=8), dict(walk_span=2, walk_waves=2), dict(walk_span=5), dict(walk_span=64, walk_waves=8),
+                     dict(walk_span=4096, walk_waves=5)):
             c, w = doppler_amd.plan_simulate(segs, rate, sn0, 128, 2, 3, options=opts)
             assert (w == 1).all() and np.array_equal(c, want), (i, opts)
             if "walk_compute" in opts and i < 3:    # tables for every matrix / for none

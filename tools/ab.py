@@ -191,6 +191,99 @@ def cases(which):
             for pair in ("i16:i16", "f32:f32"):
                 for geom in ((128, 2), (256, 1)):
                     c.append(("const %d Hz, sincos per sample" % shift, lambda f, s=shift: const_segs(s), pair, 1, dict(_geom=geom)))
+    if which == "span":          # round 3: span kernel (a workgroup keeps its window for up to walk_span rows) against the walk kernel
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for span in (1, 8, 16, 24, 32, 48, 64, 128):
+            c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, dict(walk_span=span)))
+        for span in (1, 16, 32, 64, 128, 256):
+            c.append(("const 5001 Hz", lambda f: const_segs(5001), "i16:i16", 3, dict(walk_span=span)))
+        for pair in ("f32:i16", "i16:f32", "f32:f32"):
+            for span in (1, 16, 32, 64):
+                c.append(("track 300 s replay", lambda f: track_segs(300, f), pair, 3, dict(walk_span=span)))
+        for shift in (3, 100):
+            c.append(("const %d Hz" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 3, {}))
+            for span in (32, 64):
+                c.append(("const %d Hz (walk forced)" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 5, dict(walk_span=span)))
+    if which == "exp1":          # what the sincos arithmetic costs where (run against a -DDPX_EXP_NOSINCOS build with tools/ab_libs.sh)
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for span in (1, 8, 32):
+            c.append(("track 600 s replay span=%d" % span, lambda f: track_segs(600, f), "i16:i16", 3, dict(walk_span=span)))
+        for span in (1, 32):
+            c.append(("const 5001 Hz span=%d" % span, lambda f: const_segs(5001), "i16:i16", 3, dict(walk_span=span)))
+        c.append(("const 3 Hz", lambda f: const_segs(3), "i16:i16", 3, {}))
+        c.append(("const 5001 Hz, sincos per sample", lambda f: const_segs(5001), "i16:i16", 1, {}))
+        for rows in (3, 5, 9, 25):
+            c.append(("synth %d rows of P=65536" % rows, lambda f, r=rows: synth_segs(r, total=307200000), "i16:i16", 3, dict(walk_span=1)))
+    if which == "uni":           # one-matrix launches: the matrix in the kernel arguments (walk_flags=0) against descriptors from memory (1)
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for shift in (5001, 1234, 7777.77):
+            c.append(("const %g Hz" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 3, dict(walk_span=1)))
+            for span in (8, 10, 16):
+                for fl in (0, 1):
+                    c.append(("const %g Hz" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 3, dict(walk_span=span, walk_flags=fl)))
+        for waves, span in ((5, 10), (8, 16), (2, 4)):
+            c.append(("const 5001 Hz", lambda f: const_segs(5001), "i16:i16", 3, dict(walk_span=span, walk_waves=waves)))
+        for shift in (3, 100):
+            c.append(("const %d Hz" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 3, {}))
+            for span in (8, 16):
+                c.append(("const %d Hz (walk forced)" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 5, dict(walk_span=span)))
+        for pair in ("f32:f32", "i16:f32", "f32:i16"):
+            c.append(("const 5001 Hz", lambda f: const_segs(5001), pair, 3, dict(walk_span=1)))
+            c.append(("const 5001 Hz", lambda f: const_segs(5001), pair, 3, dict(walk_span=8)))
+    if which == "pack":          # how a second's 9.06 rows are packed into wavefronts (walk kernel shapes, span kernel)
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        def alt_segs(f, a=5001.0, b=5002.0, secs=262):
+            return [(RATE, a if k % 2 == 0 else b) for k in range(secs)]
+        for waves, rows in ((4, 2), (2, 4), (3, 3), (3, 4), (4, 3), (4, 4), (5, 2), (2, 3)):
+            c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, dict(walk_span=1, walk_waves=waves, walk_rows=rows)))
+            c.append(("alternating 5001/5002 Hz seconds", alt_segs, "i16:i16", 3, dict(walk_span=1, walk_waves=waves, walk_rows=rows)))
+        for waves, span in ((4, 8), (2, 4), (5, 10)):
+            c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, dict(walk_span=span, walk_waves=waves)))
+            c.append(("alternating 5001/5002 Hz seconds", alt_segs, "i16:i16", 3, dict(walk_span=span, walk_waves=waves)))
+        c.append(("const 5001 Hz", lambda f: const_segs(5001), "i16:i16", 3, dict(walk_span=1)))
+    if which == "minl":          # const-mode walks: row length = the multiple of the period that reaches walk_flags >> 8 KiSamples
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for shift in (5001, 7777.77, 12345, 1234):
+            for minl in (0, 64, 128, 256, 512, 1024, 2048):
+                c.append(("const %g Hz" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 3, dict(walk_span=8, walk_flags=minl << 8)))
+        for shift in (100, 3):
+            for minl in (0, 128, 512, 2048):
+                c.append(("const %g Hz (walk forced)" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 5, dict(walk_span=8, walk_flags=minl << 8)))
+    if which == "policy":        # the planner's row-length rule (rows of ~1 MB / one span per second) against rows of one period (target 8 Ki)
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        OLD = 8 << 8
+        for o in (dict(), dict(walk_flags=OLD), dict(walk_span=1), dict(walk_waves=5, walk_span=10), dict(walk_waves=8, walk_span=16)):
+            c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, o))
+        for pair in ("f32:i16", "i16:f32", "f32:f32"):
+            for o in (dict(), dict(walk_flags=OLD), dict(walk_span=1)):
+                c.append(("track 300 s replay", lambda f: track_segs(300, f), pair, 3, o))
+        for shift in (5001, 7777.77, 12345, 1234, 9999, 777, -5234.17):
+            for o in (dict(), dict(walk_flags=OLD), dict(walk_span=1), dict(walk_waves=5, walk_span=10)):
+                c.append(("const %g Hz" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 3, o))
+        for pair in ("f32:i16", "i16:f32", "f32:f32"):
+            for o in (dict(), dict(walk_span=1)):
+                c.append(("const 5001 Hz", lambda f: const_segs(5001), pair, 3, o))
+    if which == "reg1":
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for o in (dict(), dict(walk_flags=8 << 8), dict(walk_span=1), dict(walk_span=1, walk_flags=8 << 8), dict(walk_waves=5, walk_span=10), dict(walk_flags=1)):
+            c.append(("const 5001 Hz", lambda f: const_segs(5001), "i16:i16", 3, o))
+        for o in (dict(), dict(walk_span=1)):
+            c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, o))
+    if which == "span3":         # span height on the replay (rows per matrix are 6-12 under the row-length rule) and in const mode
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for span in (1, 8, 10, 12, 16, 32):
+            c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, dict(walk_span=span)))
+        for span in (1, 8, 12, 16):
+            c.append(("track 300 s replay", lambda f: track_segs(300, f), "f32:i16", 3, dict(walk_span=span)))
+            c.append(("track 300 s replay", lambda f: track_segs(300, f), "i16:f32", 3, dict(walk_span=span)))
+        for span in (1, 8, 12, 16):
+            c.append(("const 5001 Hz", lambda f: const_segs(5001), "i16:i16", 3, dict(walk_span=span)))
+    if which == "span2":         # span kernel: wavefronts per workgroup
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for waves in (2, 4, 5, 8):
+            for span in (16, 32, 64):
+                c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, dict(walk_span=span, walk_waves=waves)))
+                c.append(("const 5001 Hz", lambda f: const_segs(5001), "i16:i16", 3, dict(walk_span=span, walk_waves=waves)))
     if which == "geom":          # tile-kernel geometry per format pair: sincos per sample and tile tables
         for pair in ("i16:i16", "f32:f32", "f32:i16", "i16:f32"):
             for geom in ((128, 2), (256, 1), (128, 1), (256, 2)):
@@ -204,7 +297,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
