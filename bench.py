@@ -18,6 +18,8 @@ import os
 import sys
 import time
 
+T_START = time.perf_counter()
+T_CTX = T_START
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -47,6 +49,7 @@ def cpu_baseline(x_host, gpu_out_host):
     t = time.perf_counter()
     ref, _ = orc.const_stream(xb, "i16", "i16", SHIFT, RATE, out=buf1)
     dt = time.perf_counter() - t
+    LEGS["cpu_1_core"] = round(dt, 3)
     n = x_host.size // 2
     out["value"] = round(n / dt / 1e6, 3)
     out["cores"] = 1
@@ -55,6 +58,7 @@ def cpu_baseline(x_host, gpu_out_host):
     t = time.perf_counter()
     ref_mt, _ = orc.const_stream(xb, "i16", "i16", SHIFT, RATE, threads=threads, out=buf2)
     dt_mt = time.perf_counter() - t
+    LEGS["cpu_all_cores"] = round(dt_mt, 3)
     out["all_cores"] = {"value": round(n / dt_mt / 1e6, 3), "cores": threads}
     out["sample"] = ("first %d samples (%d MiB in) of the same stream, memory to memory, 8192-byte blocks, "
                      "unpack/mix/pack passes and one cexpf per sample as in the reference; "
@@ -63,6 +67,10 @@ def cpu_baseline(x_host, gpu_out_host):
     same = bool(np.array_equal(ref, gpu_out_host.view(np.uint8)) and np.array_equal(ref_mt, ref))
     out["gpu_output_bit_exact_on_sample"] = same
     return out
+
+
+DIST_ON = False        # a process group exists (world > 1, or DPX_BENCH_FORCE_DIST=1)
+LEGS = {}              # seconds per leg of the run (rank 0), printed as `legs_s`
 
 
 TLE1 = b"1 39161U 13021C   15022.00000000  .00000500  00000-0  80000-4 0  9990"   # synthetic ESTCUBE-1-like set
@@ -132,7 +140,7 @@ def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True):
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if DIST_ON:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -158,7 +166,7 @@ def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True):
     ev1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if DIST_ON:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -169,7 +177,7 @@ def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True):
         prof = profiled("track") if world == 1 else None
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": prof["hbm_bytes_per_launch"] if prof else None,
-                "kernel": "dpx::walk_kernel" if layout["walk_launches"] else "dpx::tile_kernel", "layout": layout,
+                "kernel": "dpx::span_kernel" if layout["walk_launches"] else "dpx::tile_kernel", "layout": layout,
                 "avg_launch_ms": round(kms, 4), "algorithmic_bytes_per_launch": n * (bi + bo)}
         if prof and prof.get("avg_launch_us_kernel_trace"):
             roof["frac_rocprof"] = round(n * (bi + bo) / (prof["avg_launch_us_kernel_trace"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
@@ -190,6 +198,7 @@ def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True):
 
 
 GATHER_TIMEOUT_S = 240
+PMC_PROFILE = "r03_pmc_traffic.json"     # tools/profile_r03.sh: separate FETCH_SIZE / WRITE_SIZE passes + a kernel-trace pass
 KERNEL_SOURCES = ["doppler_amd/csrc/dpx_kernels.hip", "doppler_amd/csrc/dpx_sincos.h", "doppler_amd/csrc/dpx_types.h"]
 
 
@@ -204,9 +213,9 @@ def kernel_source_sha():
 
 
 def profiled(workload):
-    """PMC traffic and rocprofv3 kernel-trace duration of the dominant kernel from profiles/ (tools/profile_r02.sh),
+    """PMC traffic and rocprofv3 kernel-trace duration of the dominant kernel from profiles/ (tools/profile_r03.sh),
     or None when the committed profile was taken on different kernel sources."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", PMC_PROFILE)
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -228,7 +237,7 @@ def build_result(args, world, n, elapsed, avg_kernel_ms, gather, plan_ms=None, o
         "kernel": "dpx::rows_kernel<i16,i16>", "avg_launch_ms": round(avg_kernel_ms, 4),
         "algorithmic_bytes_per_launch": n * BYTES_PER_SAMPLE,
         "timing": "one HIP event pair on the launch stream around the K timed launches / K (includes the ~1.5 us inter-launch gap)",
-        "traffic_source": ("profiles/r02_pmc_traffic.json (same kernel sources: sha %s)" % kernel_source_sha()) if prof else
+        "traffic_source": ("profiles/%s (same kernel sources: sha %s)" % (PMC_PROFILE, kernel_source_sha())) if prof else
                           "none: no PMC profile of these kernel sources is committed (sha %s)" % kernel_source_sha(),
     }
     if prof and prof.get("avg_launch_us_kernel_trace"):
@@ -259,6 +268,9 @@ def build_result(args, world, n, elapsed, avg_kernel_ms, gather, plan_ms=None, o
         },
         "roofline": roof,
     }
+    # what the process group really was: the driver's SCALE record can show that RCCL saw N ranks
+    result["backend"] = dist.get_backend() if DIST_ON else None
+    result["world_size_seen"] = dist.get_world_size() if DIST_ON else 1
     if gather:
         result["gather"] = gather
     return result
@@ -286,8 +298,16 @@ def main():
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # DPX_BENCH_FORCE_DIST=1: take the multi-rank branch (RCCL process group, barrier, all_reduce(MAX), ordered gather,
+    # per-GPU D2H) even with ONE rank, so that the code the driver's 2/4/8-GPU runs execute has run under RCCL on a one-GPU box
+    global DIST_ON
+    DIST_ON = world > 1 or os.environ.get("DPX_BENCH_FORCE_DIST") == "1"
+    if DIST_ON:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if share:
             dist.init_process_group(backend="gloo")
         else:
@@ -297,9 +317,11 @@ def main():
     from doppler_amd import shard
 
     ctx = doppler_amd.Context(dev_index)
+    global T_CTX
+    T_CTX = time.perf_counter()
     if args.workload == "track":
         run_track(args, world, rank, dev, ctx)
-        if world > 1:
+        if DIST_ON:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -308,12 +330,14 @@ def main():
     # counter seeded from the closed form of dsp.rs:125-130
     lo, hi = shard.chunk_bounds(world * n, world, rank)
     assert (lo, hi) == (rank * n, (rank + 1) * n)
+    t_leg = time.perf_counter()
     gen = torch.Generator(device=dev)
     gen.manual_seed(0xD0BB1E5 + rank)
     x = torch.randint(-23170, 23171, (2 * n,), dtype=torch.int16, device=dev, generator=gen)
     out = torch.empty(2 * n, dtype=torch.int16, device=dev)
     stream = torch.cuda.current_stream(dev)
     torch.cuda.synchronize(dev)
+    LEGS["generate"] = round(time.perf_counter() - t_leg, 3)
     # plan (host: closed-form seed + period scan + launch list; device: descriptor upload, corrector table) and the very
     # first launch, timed once: what a one-shot caller pays; the timed region below re-launches the resident plan
     t_plan = time.perf_counter()
@@ -329,7 +353,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if DIST_ON:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -347,7 +371,8 @@ def main():
     ev1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    LEGS["timed"] = round(elapsed, 4)
+    if DIST_ON:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -355,7 +380,8 @@ def main():
 
     # ---- outside the timed region: ordered gather (multi-GPU), host round trip, CPU baseline
     gather = None
-    if world > 1:
+    t_leg = time.perf_counter()
+    if DIST_ON:
         # The gather is reported beside `value`, never inside it.  A watchdog keeps a stuck transfer from
         # swallowing the measurement: after GATHER_TIMEOUT_S every rank gives up and rank 0 prints its line without it.
         import threading
@@ -408,12 +434,14 @@ def main():
             gather["per_gpu_d2h"] = {"error": str(e)[:300]}
         gather_state["done"] = True
         timer.cancel()
+        LEGS["gather"] = round(time.perf_counter() - t_leg, 3)
 
     result = None
     if rank == 0:
         result = build_result(args, world, n, elapsed, avg_kernel_ms, gather, round(plan_ms, 3), round(one_shot_ms, 3))
         if world == 1:
             # PCIe-inclusive figure (never `value`): pinned host -> HBM -> kernel -> pinned host
+            t_leg = time.perf_counter()
             try:
                 hx = torch.empty(2 * n, dtype=torch.int16).pin_memory()
                 ho = torch.empty(2 * n, dtype=torch.int16).pin_memory()
@@ -430,13 +458,17 @@ def main():
                 del hx, ho
             except Exception as e:  # pinning 2 GiB can fail on small hosts; the headline does not depend on it
                 result["host_round_trip"] = {"error": str(e)[:200]}
+            LEGS["host_round_trip"] = round(time.perf_counter() - t_leg, 3)     # pinning 2 x 1 GiB is most of it
             if not args.no_cpu:
+                t_leg = time.perf_counter()
                 m = min(CPU_SAMPLE, n)
                 xh = x[: 2 * m].cpu().numpy()
                 oh = out[: 2 * m].cpu().numpy()
                 result["cpu_baseline"] = cpu_baseline(xh, oh)
+                LEGS["cpu_baseline"] = round(time.perf_counter() - t_leg, 3)
             del x, out
             torch.cuda.empty_cache()
+            t_leg = time.perf_counter()
             if not args.no_extra:
                 # secondary workload (BASELINE.json configs[2]), after the timed region: rides along in the driver's record
                 try:
@@ -444,10 +476,13 @@ def main():
                                                           warmup=min(args.warmup, 3), emit=False)}
                 except Exception as e:
                     result["extra"] = {"track": {"error": str(e)[:300]}}
+                LEGS["extra_track"] = round(time.perf_counter() - t_leg, 3)
+        LEGS["import_and_context"] = round(T_CTX - T_START, 3)
+        result["legs_s"] = dict(LEGS)
         print(json.dumps(result), flush=True)
 
     plan.close()
-    if world > 1:
+    if DIST_ON:
         dist.barrier()
         dist.destroy_process_group()
 

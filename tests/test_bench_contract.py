@@ -31,3 +31,5 @@ def test_result_line_schema():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["achieved"] - n * 8 / 0.3204e-3 / 1e9) < 0.1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["algorithmic_bytes_per_launch"] == n * 8 and line["gather"] == {"ms": 12.5}
+    # no process group in this test: the line says so (under the driver: "nccl" and the world RCCL reported)
+    assert line["backend"] is None and line["world_size_seen"] == 1

@@ -121,3 +121,30 @@ def test_bench_multi_rank_code_path_on_a_shared_gpu():
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
     assert line["config"]["samples_per_gpu"] == 268435456
     assert "roofline" in line and "gather" in line
+
+
+def test_bench_rccl_branch_with_one_rank():
+    """The branch the driver's 2/4/8-GPU runs take — init_process_group(backend="nccl", device_id=...), dist.barrier,
+    all_reduce(MAX) of the elapsed time, the ordered gather (batch_isend_irecv path) and the per-GPU D2H leg — run under a
+    real RCCL with ONE rank (DPX_BENCH_FORCE_DIST=1), launched through torch.distributed.run exactly like the driver does.
+    The JSON line names the backend and the world size the process group reported."""
+    env = dict(os.environ, DPX_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("DPX_BENCH_SHARE_GPU", None)
+    port = 29400 + (os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu", "--no-extra"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["backend"] == "nccl" and line["world_size_seen"] == 1 and line["n_gpus"] == 1
+    assert "error" not in line["gather"] and "error" not in line["gather"]["per_gpu_d2h"], line["gather"]
+    assert line["gather"]["ms"] > 0 and line["roofline"]["frac"] > 0.5
+    # and the track workload's barrier / all_reduce under the same process group
+    cmd = cmd[:-2] + ["--workload", "track"]
+    cmd[cmd.index("--master-port") + 1] = str(port + 1)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["roofline"]["frac"] > 0.4
