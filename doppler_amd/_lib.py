@@ -104,6 +104,7 @@ _SIGNATURES = {
     "dpx_debug_copy": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "dpx_set_tuning": (_i, [_vp, _i, _i, _i]),
     "dpx_set_libm_contraction": (_i, [_vp, _i]),
+    "dpx_set_i16_cast": (_i, [_vp, _i]),
     "dpx_malloc": (_i, [_vp, _sz, _P(_vp)]),
     "dpx_free": (_i, [_vp, _vp]),
     "dpx_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),

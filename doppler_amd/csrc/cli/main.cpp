@@ -52,8 +52,11 @@
 namespace {
 
 // fern format of the reference (main.rs:220-223): "{ts}.{ms:3} [{level:<6} {module:<30} {line:>3}]  {msg}"
+// module: the binary's crate name, as module_path!() gives it for main.rs; line: the call site (this file's — the
+// reference prints main.rs's own line numbers, e.g. 103 for the banner)
 std::mutex g_log_mu;
-void info(const char *fmt, ...)
+#define info(...) info_at(__LINE__, __VA_ARGS__)
+void info_at(int line, const char *fmt, ...)
 {
     struct timeval tv;
     gettimeofday(&tv, nullptr);
@@ -62,7 +65,7 @@ void info(const char *fmt, ...)
     char ts[32];
     strftime(ts, sizeof(ts), "%Y-%m-%dT%H:%M:%S", &tmv);
     std::lock_guard<std::mutex> lk(g_log_mu);
-    fprintf(stderr, "%s.%3d [%-6s %-30s %3d]  ", ts, (int)(tv.tv_usec / 1000), "INFO", "doppler", 0);
+    fprintf(stderr, "%s.%3d [%-6s %-30s %3d]  ", ts, (int)(tv.tv_usec / 1000), "INFO", "doppler", line);
     va_list ap;
     va_start(ap, fmt);
     vfprintf(stderr, fmt, ap);
@@ -273,7 +276,14 @@ int main(int argc, char **argv)
     std::vector<int> devices;
     if (const char *e = getenv("DOPPLER_DEVICES")) {
         for (const char *p = e; *p;) {
-            devices.push_back((int)strtol(p, const_cast<char **>(&p), 10));
+            char *end = nullptr;
+            const long d = strtol(p, &end, 10);
+            if (end == p || d < 0 || d > 1023 || devices.size() >= 64) {       // not a number: strtol made no progress
+                fprintf(stderr, "doppler: DOPPLER_DEVICES must be a comma-separated list of device numbers, got \"%s\"\n", e);
+                return 1;
+            }
+            devices.push_back((int)d);
+            p = end;
             while (*p == ',' || *p == ' ') ++p;
         }
     }
@@ -297,6 +307,17 @@ int main(int argc, char **argv)
         ctxs.push_back(c);
     }
     if (n_gpus > 1) info("\tGPUs            : %u", n_gpus);
+    // DOPPLER_I16_CAST=legacy: `as i16` as a 2016 rustc compiled it for x86-64 (out-of-range samples wrap instead of
+    // saturating) — for byte-for-byte comparisons with files written by binaries of that time (include/doppler_hip.h)
+    if (const char *e = getenv("DOPPLER_I16_CAST")) {
+        const bool legacy = !strcmp(e, "legacy") || !strcmp(e, "wrap");
+        if (!legacy && strcmp(e, "saturate") != 0) {
+            fprintf(stderr, "doppler: DOPPLER_I16_CAST must be \"saturate\" (default) or \"legacy\", got \"%s\"\n", e);
+            destroy_ctxs();
+            return 1;
+        }
+        for (dpx_ctx *c : ctxs) dpx_set_i16_cast(c, legacy ? DPX_CAST_LEGACY_X86 : DPX_CAST_SATURATE);
+    }
 
     const bool replay = args.mode == dpx::Mode::Track && args.has_time;
     const bool live_track = args.mode == dpx::Mode::Track && !args.has_time;

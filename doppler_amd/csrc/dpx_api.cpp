@@ -54,6 +54,7 @@ struct dpx_ctx {
     bool geom_auto = true;    // until dpx_set_tuning names a geometry: chosen per launch (run_plan)
     int variant = 0;
     int choice = dpx::kChooseAuto;   // which kernels finalize() may use (dpx_set_tuning)
+    int i16_cast = DPX_CAST_SATURATE;   // meaning of `as i16` (dpx_set_i16_cast); the legacy one confines plans to the tile kernel
     dpx::PlanTuning tuning;          // kernel-shape knobs (dpx_set_options)
     dpx::PeriodCache periods;        // period per ratio seen so far (one producer thread plans at a time)
     hipStream_t stream = nullptr;   // internal stream of the host-pointer entry points
@@ -112,12 +113,17 @@ int ensure_stage(dpx_ctx *ctx, size_t in_bytes, size_t out_bytes)
     return DPX_OK;
 }
 
+// the legacy cast exists in the tile kernel only
+int plan_choice(const dpx_ctx *ctx) { return ctx->i16_cast == DPX_CAST_LEGACY_X86 ? (int)dpx::kChooseTileOnly : ctx->choice; }
+
 dpx::LaunchGeom geometry(const dpx_ctx *ctx)
 {
     dpx::LaunchGeom g;
     g.block = ctx->block;
     g.vecs = ctx->vecs;
     g.autosel = ctx->geom_auto ? 1 : 0;
+    g.legacy_cast = ctx->i16_cast == DPX_CAST_LEGACY_X86 ? 1 : 0;
+    if (g.legacy_cast) { g.block = 256; g.vecs = 1; g.autosel = 0; }
     return g;
 }
 
@@ -318,7 +324,7 @@ int run_host(dpx_ctx *ctx, const void *in, size_t n, int in_fmt, void *out, int 
         return DPX_OK;
     }
     const dpx::LaunchGeom g = geometry(ctx);
-    dpx::finalize(plan, g.tile(), ctx->choice, ctx->tuning);
+    dpx::finalize(plan, g.tile(), plan_choice(ctx), ctx->tuning);
     if (plan.error) return fail(DPX_ERR_PLAN, "%s", plan.error);
     const size_t in_bytes = n * bytes_per_sample(in_fmt), out_bytes = n * bytes_per_sample(out_fmt);
     int rc = ensure_stage(ctx, in_bytes, out_bytes);
@@ -351,7 +357,7 @@ int run_host_segments(dpx_ctx *ctx, const void *in, int in_fmt, void *out, int o
         return DPX_OK;
     }
     const dpx::LaunchGeom g = geometry(ctx);
-    dpx::finalize(plan, g.tile(), ctx->choice, ctx->tuning);
+    dpx::finalize(plan, g.tile(), plan_choice(ctx), ctx->tuning);
     if (plan.error) return fail(DPX_ERR_PLAN, "%s", plan.error);
     const size_t in_bytes = n * bytes_per_sample(in_fmt), out_bytes = n * bytes_per_sample(out_fmt);
     int rc = ensure_stage(ctx, in_bytes, out_bytes);
@@ -480,6 +486,14 @@ int dpx_set_options(dpx_ctx *ctx, const dpx_options *opt)
     return DPX_OK;
 }
 
+int dpx_set_i16_cast(dpx_ctx *ctx, int mode)
+{
+    if (!ctx) return fail(DPX_ERR_ARG, "ctx is null");
+    if (mode != DPX_CAST_SATURATE && mode != DPX_CAST_LEGACY_X86) return fail(DPX_ERR_ARG, "unknown i16 cast mode %d", mode);
+    ctx->i16_cast = mode;
+    return DPX_OK;
+}
+
 int dpx_set_libm_contraction(dpx_ctx *ctx, int fma)
 {
     if (!ctx) return fail(DPX_ERR_ARG, "ctx is null");
@@ -583,7 +597,7 @@ int dpx_pack_iqi16(dpx_ctx *ctx, const dpx_complex32 *inbuf, size_t n, uint8_t *
     int rc = ensure_stage(ctx, n * 8, n * 4);
     if (rc != DPX_OK) return rc;
     DPX_HIP(hipMemcpyAsync(ctx->stage_in, inbuf, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    rc = dpx::launch_pack_i16(ctx->stage_in, ctx->stage_out, n, ctx->stream);
+    rc = dpx::launch_pack_i16(ctx->stage_in, ctx->stage_out, n, ctx->stream, ctx->i16_cast == DPX_CAST_LEGACY_X86);
     if (rc != DPX_OK) return fail(rc, "kernel launch failed");
     DPX_HIP(hipMemcpyAsync(out, ctx->stage_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     DPX_HIP(hipStreamSynchronize(ctx->stream));
@@ -802,7 +816,7 @@ int dpx_plan_segments(dpx_ctx *ctx, const dpx_segment *segs, size_t n_segs, uint
     uint32_t sn = samplenum0;
     p->host.final_samplenum = sn;
     append_segments(p->host, segs, n_segs, samplerate, sn, ctx->variant, ctx->periods);
-    dpx::finalize(p->host, p->geom.tile(), ctx->choice, ctx->tuning);
+    dpx::finalize(p->host, p->geom.tile(), plan_choice(ctx), ctx->tuning);
     hipError_t e = hipSetDevice(ctx->device);
     int rc = e == hipSuccess ? DPX_OK : fail(DPX_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
     if (rc == DPX_OK && p->host.error) rc = fail(DPX_ERR_PLAN, "%s", p->host.error);
@@ -993,7 +1007,7 @@ int dpx_stream_submit(dpx_stream *s, size_t in_bytes, const dpx_segment *segs, s
     // the context remembers every ratio's period: a constant shift is scanned once per run, not once per slab
     append_segments(b.plan, segs, n_segs, s->samplerate, sn, ctx->variant, ctx->periods);
     const dpx::LaunchGeom g = geometry(ctx);
-    dpx::finalize(b.plan, g.tile(), ctx->choice, ctx->tuning);
+    dpx::finalize(b.plan, g.tile(), plan_choice(ctx), ctx->tuning);
     if (b.plan.error) return fail(DPX_ERR_PLAN, "%s", b.plan.error);
     b.out_bytes = (size_t)total * obs;
     if (total) {

@@ -22,6 +22,12 @@
 
 #pragma clang fp contract(off)
 
+// gfx950 only: the inline assembly (v_pk_mul_f32 op_sel, v_bitop3_b32, v_cvt_pk_i16_i32), the kernarg preload and the
+// LDS layouts below are written for CDNA4's 64-wide wavefronts; there is no other device path.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "dpx_kernels.hip is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 #ifndef DPX_WALK_ACTIVE_ONLY
 #define DPX_WALK_ACTIVE_ONLY 1
 #endif
@@ -89,11 +95,19 @@ __device__ __forceinline__ int f32_as_i32_sat(float x)
 }
 
 // main.rs:77-83: i = (re * 32767.0) as i16, little-endian I then Q.
-template <bool RAW = false>
+// LEGACY (dpx_set_i16_cast(DPX_CAST_LEGACY_X86); tile kernel and the pack operator only): the cast as a 2016 rustc compiled
+// it for x86-64 — CVTTSS2SI into a 32-bit register, low half kept: truncate, then wrap modulo 2^16; NaN and |x| >= 2^31
+// give 0x80000000, low half 0.  v_cvt_i32_f32 differs from CVTTSS2SI only at x >= 2^31 (0x7fffffff: low half 0xffff).
+template <bool RAW = false, bool LEGACY = false>
 __device__ __forceinline__ uint32_t pack_i16(float re, float im)
 {
     constexpr float K = RAW ? 0x1.fffcp-1f /* 32767 / 32768, exact */ : 32767.0f;
     const f32x2 sc = f32x2{re, im} * K;                  // one v_pk_mul_f32, each product rounded on its own
+    if constexpr (LEGACY) {
+        const uint32_t i = sc.x >= 2147483648.0f ? 0u : (uint32_t)f32_as_i32_sat(sc.x);
+        const uint32_t q = sc.y >= 2147483648.0f ? 0u : (uint32_t)f32_as_i32_sat(sc.y);
+        return (i & 0xffffu) | (q << 16);
+    }
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     const s16x2 p = __builtin_amdgcn_cvt_pk_i16(f32_as_i32_sat(sc.x), f32_as_i32_sat(sc.y));
     return __builtin_bit_cast(uint32_t, p);
@@ -135,11 +149,11 @@ __device__ __forceinline__ void quad_get(const Quad<FMT> &q, int k, float &re, f
     }
 }
 
-template <int FMT, bool RAW = false>
+template <int FMT, bool RAW = false, bool LEGACY = false>
 __device__ __forceinline__ void quad_set(Quad<FMT> &q, int k, float re, float im)
 {
     if constexpr (FMT == DPX_FMT_I16) {
-        q.v[0][k] = pack_i16<RAW>(re, im);
+        q.v[0][k] = pack_i16<RAW, LEGACY>(re, im);
     } else {   // main.rs:91: raw reinterpret
         q.v[k >> 1][(k & 1) * 2] = __float_as_uint(re);
         q.v[k >> 1][(k & 1) * 2 + 1] = __float_as_uint(im);
@@ -159,11 +173,11 @@ __device__ __forceinline__ void load_one(const uint8_t *base, uint64_t g, float 
     }
 }
 
-template <int FMT, bool RAW = false>
+template <int FMT, bool RAW = false, bool LEGACY = false>
 __device__ __forceinline__ void store_one(uint8_t *base, uint64_t g, float re, float im)
 {
     if constexpr (FMT == DPX_FMT_I16) {
-        *reinterpret_cast<uint32_t *>(base + g * 4) = pack_i16<RAW>(re, im);
+        *reinterpret_cast<uint32_t *>(base + g * 4) = pack_i16<RAW, LEGACY>(re, im);
     } else {
         u32x2 w;
         w[0] = __float_as_uint(re);
@@ -199,7 +213,7 @@ __device__ __forceinline__ uint32_t counter_at(const DevSeg &sg, uint64_t j)
 //   * tile kernel: whatever the two above leave.
 
 // ---- per-sample evaluation (ragged ranges and stretch boundaries)
-template <int IN_FMT, int OUT_FMT, bool FMA>
+template <int IN_FMT, int OUT_FMT, bool FMA, bool LEGACY = false>
 __device__ __forceinline__ void one_sample(const uint8_t *in, uint8_t *out, const DevSeg *segs,
                                            uint32_t n_segs, uint32_t si, uint64_t g)
 {
@@ -209,7 +223,7 @@ __device__ __forceinline__ void one_sample(const uint8_t *in, uint8_t *out, cons
     corrector<FMA>(sx.ratio, counter_at(sx, g - sx.first), c, s);
     load_one<IN_FMT, kRawI16<IN_FMT, OUT_FMT>>(in, g, a, b);
     mix(a, b, c, s, re, im);
-    store_one<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(out, g, re, im);
+    store_one<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>, LEGACY>(out, g, re, im);
 }
 
 // ---- rows kernel: one wavefront, R rows of one tabulated periodic stretch
@@ -347,7 +361,7 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
 }
 
 // ---- tile kernel: any mixture of stretches; workgroup b handles tile tile_lo + b and exits
-template <int IN_FMT, int OUT_FMT, bool FMA, int BLOCK, int V>
+template <int IN_FMT, int OUT_FMT, bool FMA, int BLOCK, int V, bool LEGACY = false>
 __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__ in,
                                                      uint8_t *__restrict__ out,
                                                      const DevSeg *__restrict__ segs,
@@ -399,7 +413,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
                 float a, b, re, im;
                 quad_get<IN_FMT, kRawI16<IN_FMT, OUT_FMT>>(qin[v], k, a, b);
                 mix(a, b, cs[k].x, cs[k].y, re, im);
-                quad_set<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(qo, k, re, im);
+                quad_set<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>, LEGACY>(qo, k, re, im);
             }
             store_quad<OUT_FMT>(out, t0 + (uint64_t)(v * BLOCK + tid) * SPL, qo);
         }
@@ -453,7 +467,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
                 float a, b, re, im;
                 quad_get<IN_FMT, kRawI16<IN_FMT, OUT_FMT>>(qin[v], k, a, b);
                 mix(a, b, cs[k].x, cs[k].y, re, im);
-                quad_set<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(qo, k, re, im);
+                quad_set<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>, LEGACY>(qo, k, re, im);
             }
             store_quad<OUT_FMT>(out, t0 + (uint64_t)(v * BLOCK + tid) * SPL, qo);
         }
@@ -463,7 +477,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
             const uint64_t g = t0 + o;
             if (g < ta.m0) continue;
             if (g >= ta.m1) break;
-            one_sample<IN_FMT, OUT_FMT, FMA>(in, out, segs, n_segs, si, g);
+            one_sample<IN_FMT, OUT_FMT, FMA, LEGACY>(in, out, segs, n_segs, si, g);
         }
     }
 }
@@ -534,28 +548,20 @@ __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_
     typedef SlicePlanes<S, kEntries> SP;
 
     const uint32_t r0 = ws.row0 + wave * U;
-    // A wavefront past the last row of the chunk has nothing to do; unless it produces part of the slice (the first
-    // kWalkSlice / 2 threads load it, or the first kWalkSlice threads evaluate it) it leaves at once.  s_barrier counts
-    // the wavefronts of the workgroup that have not terminated (CDNA ISA, S_BARRIER: a wave that has ended is no
-    // longer waited for), so the survivors' barrier completes; tests/test_gpu_parity.py runs every workgroup shape
-    // with row counts that leave 1..WAVES-1 wavefronts without rows.
-    // Measured alternative (profiles/r02_walk.md): only the wavefronts WITH rows evaluate the slice, so that the others
-    // leave at once — slower everywhere (the serial evaluations delay the surviving wavefronts past their loads).
+    // A wavefront past the last row of the chunk has nothing to load; it still reaches the workgroup's barrier (rounds 1
+    // and 2 let it end before the barrier, relying on s_barrier counting live wavefronts only — hardware behaviour the
+    // language does not promise; the span kernel, which serves every default plan now, never did).
+    const bool idle = r0 >= ws.row_end;                            // uniform
 #if DPX_WALK_ACTIVE_ONLY
-    // Evaluated slices: the wavefronts WITH rows share the evaluation; one without rows leaves at once instead of
-    // holding its slot until the barrier (a 9-row second fills 5 of 8 wavefronts: every one-second matrix has such
-    // chunks).  The shared loop is unrolled with a compile-time trip count — a loop with a run-time stride makes the
-    // compiler wait for the sample loads at its entry.
+    // Evaluated slices: the wavefronts WITH rows share the evaluation.  The shared loop is unrolled with a compile-time
+    // trip count — a loop with a run-time stride makes the compiler wait for the sample loads at its entry.
     const uint32_t n_act = (ws.row_end - ws.row0 + U - 1) / U;      // wavefronts with rows: 1..WAVES (uniform)
-    if (r0 >= ws.row_end && (compute || wave * kRowsLanes >= kEntries / 2)) return;
-#else
-    const uint32_t slice_threads = compute ? kEntries : kEntries / 2;
-    if (r0 >= ws.row_end && wave * kRowsLanes >= slice_threads) return;
 #endif
     qvec qin[U][NV];
     uint32_t off[U];                                          // slice entry of the row's column 0 (uniform per wavefront)
     uint8_t *op[U][NV];
     uint8_t *opx[U];                                          // f32 -> i16: where this lane's 4 consecutive samples go
+    if (!idle) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const bool valid = r0 + u < ws.row_end;
@@ -577,8 +583,9 @@ __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_
         const uint32_t c4 = col0 + lane * 4;
         opx[u] = c4 < rowlen ? out + (row0 + c4) * OB : sink + tid * 16;
     }
+    }
 
-    if (compute) {                                            // uniform for the workgroup
+    if (compute && !(DPX_WALK_ACTIVE_ONLY && idle)) {         // uniform for the wavefront
         // thread j evaluates entry j (threads 0..31 also entry 256 + j) with the bit-exact sincos — after the sample
         // loads above have been issued, so the evaluation runs in the shadow of the HBM latency
         const uint32_t P = ws.period;
@@ -610,7 +617,7 @@ __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_
                 slice[SP::index(j)] = make_float2(c, sn);
             }
         }
-    } else {
+    } else if (!compute) {
 #pragma unroll
         for (int i = 0; i < TL; ++i) {
             const uint32_t j = tid + (uint32_t)i * THREADS;
@@ -621,7 +628,7 @@ __device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_
         }
     }
     __syncthreads();
-    if (r0 >= ws.row_end) return;                             // a wavefront past the last row (uniform)
+    if (idle) return;                                         // a wavefront past the last row (uniform), after the barrier
 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1150,11 +1157,11 @@ __global__ __launch_bounds__(kBlock) void unpack_i16_kernel(const uint32_t *__re
 
 // main.rs:72-87 on its own
 __global__ __launch_bounds__(kBlock) void pack_i16_kernel(const float2 *__restrict__ in,
-                                                          uint32_t *__restrict__ out, uint64_t n)
+                                                          uint32_t *__restrict__ out, uint64_t n, int legacy)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
         const float2 z = in[i];
-        out[i] = pack_i16(z.x, z.y);
+        out[i] = legacy ? pack_i16<false, true>(z.x, z.y) : pack_i16(z.x, z.y);
     }
 }
 
@@ -1202,6 +1209,11 @@ static int tiles_t(const void *d_in, void *d_out, const DevSeg *d_segs, uint32_t
     if (t.n_tiles == 0) return DPX_OK;
     if (t.n_tiles > 0x7fffffffull) return DPX_ERR_ARG;
     const dim3 grid((uint32_t)t.n_tiles);
+    if (g.legacy_cast && OUT_FMT == DPX_FMT_I16) {      // the 2016 meaning of `as i16`: one geometry, tile kernel only
+        if (fma) tile_kernel<IN_FMT, OUT_FMT, true, 256, 1, true><<<grid, 256, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t);
+        else     tile_kernel<IN_FMT, OUT_FMT, false, 256, 1, true><<<grid, 256, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t);
+        return g.tile() == 1024u && hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;
+    }
 #define DPX_CASE(B, Vv)                                                                                      \
     if (g.block == B && g.vecs == Vv) {                                                                      \
         if (fma) tile_kernel<IN_FMT, OUT_FMT, true, B, Vv><<<grid, B, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t);  \
@@ -1351,10 +1363,10 @@ int launch_unpack_i16(const void *d_in, void *d_out, uint64_t n, void *stream)
     return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;
 }
 
-int launch_pack_i16(const void *d_in, void *d_out, uint64_t n, void *stream)
+int launch_pack_i16(const void *d_in, void *d_out, uint64_t n, void *stream, int legacy_cast)
 {
     pack_i16_kernel<<<aux_grid(n), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
-        static_cast<const float2 *>(d_in), static_cast<uint32_t *>(d_out), n);
+        static_cast<const float2 *>(d_in), static_cast<uint32_t *>(d_out), n, legacy_cast);
     return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;
 }
 

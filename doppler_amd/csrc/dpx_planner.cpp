@@ -88,11 +88,9 @@ bool find_reset(float ratio, uint32_t n_start, uint64_t max_scan, uint32_t *n_re
 // first reset from counter 1 on, remembered per ratio (bit pattern): the period of every steady stretch with that ratio.
 // Only candidates below `limit` are ever scanned (a caller never needs to know about resets beyond its own samples);
 // what has been scanned without finding one is remembered too.  Returns 0 if there is no reset in [1, limit).
-uint32_t PeriodCache::period(float ratio, uint64_t limit)
+// scan one entry further (no map access: what the worker threads of prefetch() run on entries they own)
+static uint32_t scan_entry(PeriodCache::Entry &e, float ratio, uint64_t limit)
 {
-    uint32_t bits;
-    memcpy(&bits, &ratio, sizeof bits);
-    Entry &e = first_reset[bits];               // {0, 1} when new: nothing found, scanned up to (excluding) 1
     if (e.period != 0) return e.period < limit ? e.period : 0;
     limit = std::min<uint64_t>(limit, 1ULL << 32);
     if (e.scanned_to >= limit) return 0;
@@ -105,18 +103,43 @@ uint32_t PeriodCache::period(float ratio, uint64_t limit)
     return 0;
 }
 
+// The cache is bounded: a live `doppler track` re-evaluates the shift for every 8 KiB block, so almost every block
+// brings a new ratio (hundreds per second) and a context lives for days.  An entry only has to survive while its plan
+// is being built, so a full cache is simply emptied (the next lookups scan again: microseconds to milliseconds each).
+void PeriodCache::make_room(size_t incoming)
+{
+    if (first_reset.size() + incoming > kMaxEntries) first_reset.clear();
+}
+
+uint32_t PeriodCache::period(float ratio, uint64_t limit)
+{
+    uint32_t bits;
+    memcpy(&bits, &ratio, sizeof bits);
+    auto it = first_reset.find(bits);
+    if (it == first_reset.end()) {
+        make_room(1);
+        it = first_reset.emplace(bits, Entry()).first;      // {0, 1}: nothing found, scanned up to (excluding) 1
+    }
+    return scan_entry(it->second, ratio, limit);
+}
+
 // Periods of many ratios at once: the scans are independent of each other (only the lead-ins of plan_append depend on
 // the carried counter), so a long segment list — a track replay has one ratio per second of stream — is scanned on
 // several host threads before the sequential pass, which then finds every period in the cache.
 void PeriodCache::prefetch(const float *ratios, const uint64_t *counts, size_t n)
 {
-    std::vector<std::pair<float, uint64_t>> todo;
+    struct Todo { Entry *e; float ratio; uint64_t limit; };
+    std::vector<Todo> todo;
+    if (n > kMaxEntries) return;                             // more ratios than the cache holds: plan_append scans on demand
+    make_room(n);
     for (size_t i = 0; i < n; ++i) {
         uint32_t bits;
         memcpy(&bits, &ratios[i], sizeof bits);
         if (first_reset.find(bits) != first_reset.end()) continue;
-        first_reset[bits];                                   // entries exist before the threads start: no insertions later
-        todo.push_back({ratios[i], counts[i] + 1});
+        // every entry exists before the threads start, and the threads work through pointers to their own entries:
+        // the map itself is not touched while they run (node-based container: the pointers stay valid)
+        Entry *e = &first_reset.emplace(bits, Entry()).first->second;
+        todo.push_back({e, ratios[i], counts[i] + 1});
     }
     const size_t hw = std::max(1u, std::thread::hardware_concurrency());
     const size_t n_threads = std::min<size_t>({hw, 16, todo.size() / 8});
@@ -124,7 +147,7 @@ void PeriodCache::prefetch(const float *ratios, const uint64_t *counts, size_t n
     std::vector<std::thread> pool;
     for (size_t t = 0; t < n_threads; ++t)
         pool.emplace_back([&, t] {
-            for (size_t i = t; i < todo.size(); i += n_threads) period(todo[i].first, todo[i].second);   // distinct entries
+            for (size_t i = t; i < todo.size(); i += n_threads) scan_entry(*todo[i].e, todo[i].ratio, todo[i].limit);
         });
     for (std::thread &th : pool) th.join();
 }

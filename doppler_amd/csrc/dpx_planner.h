@@ -90,6 +90,8 @@ struct PlanResult {
 struct PeriodCache {
     struct Entry { uint32_t period = 0; uint64_t scanned_to = 1; };
     std::unordered_map<uint32_t, Entry> first_reset;
+    static constexpr size_t kMaxEntries = 16384;      // bounded: emptied when full (a live track stream brings a new ratio per block)
+    void make_room(size_t incoming);
     uint32_t period(float ratio, uint64_t limit);     // first reset in [1, limit), or 0
     void prefetch(const float *ratios, const uint64_t *counts, size_t n);   // scan many ratios on several threads
 };

@@ -59,6 +59,7 @@ struct LaunchGeom {
     int block;    // 128 or 256 lanes per workgroup
     int vecs;     // 4-sample groups per lane: 1 or 2
     int autosel = 0;   // the caller set neither: 128 x 2 or 256 x 1 (the same 1024-sample tile) is chosen per launch
+    int legacy_cast = 0;   // dpx_set_i16_cast(DPX_CAST_LEGACY_X86): i16 output wraps instead of saturating (tile-only plans)
     uint32_t tile() const { return (uint32_t)block * kSamplesPerLane * (uint32_t)vecs; }
 };
 
@@ -99,7 +100,7 @@ struct RowsArgs {
 // table per sample, cold, because all tiles of a one-second stretch are in flight at once).  Row r is shifted left by
 // delta_r = (A + r * L) mod 32 samples, so its lanes index the table at kWalkPad - delta_r + column.
 // The launch is a list of row chunks (WalkSeg), stretch by stretch, each chunk padded to a multiple of 8 workgroups.
-struct WalkSeg {           // one row chunk (kWalkWaves x kWalkRowsPerWave = 10 rows) of one stretch's matrix
+struct WalkSeg {           // one span (span kernel: up to 12 rows) or row chunk (walk kernel: waves x rows per wavefront) of one stretch's matrix
     uint64_t A;            // first sample of the matrix (multiple of 32)
     uint64_t E;            // one past its last sample (multiple of 32)
     uint32_t L;            // row length in samples
@@ -189,7 +190,7 @@ int launch_build_lut(void *d_lut_entries, uint32_t period, uint32_t n_first, uin
                      float ratio, bool fma, void *stream);
 int launch_copy(const void *d_in, void *d_out, uint64_t n_bytes, void *stream);
 int launch_unpack_i16(const void *d_in, void *d_out, uint64_t n_samples, void *stream);
-int launch_pack_i16(const void *d_in, void *d_out, uint64_t n_samples, void *stream);
+int launch_pack_i16(const void *d_in, void *d_out, uint64_t n_samples, void *stream, int legacy_cast = 0);
 int launch_ccexpf_imag(void *d_z, uint64_t n, bool fma, void *stream);
 int launch_ccexpf(void *d_z, uint64_t n, bool fma, void *stream);
 

@@ -79,6 +79,11 @@ class Context:
     def set_libm_contraction(self, fma=True):
         check(self._lib.dpx_set_libm_contraction(self._h, 1 if fma else 0))
 
+    def set_i16_cast(self, legacy_x86=False):
+        """Meaning of `(x * 32767.0) as i16` (main.rs:77-78) outside the i16 range: saturate (Rust >= 1.45, default) or
+        truncate-and-wrap (the x86-64 code of a 2016 rustc). Applies to plans created afterwards."""
+        check(self._lib.dpx_set_i16_cast(self._h, 1 if legacy_x86 else 0))
+
     # ---- device memory helpers (for callers without torch)
     def malloc(self, nbytes):
         p = C.c_void_p()

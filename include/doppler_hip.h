@@ -119,7 +119,7 @@ typedef struct dpx_options {
     uint32_t rows_mult;      /* rows kernel: row length = rows_mult * lcm(period, 4) samples */
     uint32_t rows_maxl;      /* rows kernel: longest row considered */
     uint32_t rows_r;         /* rows kernel: rows per wavefront (2, 4 or 8) */
-    uint32_t walk_waves;     /* walk kernel: wavefronts per workgroup (4, 5, 6 or 8) */
+    uint32_t walk_waves;     /* walk kernel: wavefronts per workgroup (2, 3, 4, 5, 6 or 8); span kernel: 2, 4, 5 or 8 */
     uint32_t walk_rows;      /* walk kernel: most rows per wavefront a chunk may use (1..4) */
     int32_t walk_compute;    /* walk kernel: 1 = workgroups always evaluate their corrector slices, 0 = always plan-time tables,
                               * -1 = per matrix (tables for matrices of at least walk_table_rows rows) */
@@ -270,7 +270,7 @@ int dpx_debug_copy(dpx_ctx *ctx, const void *d_in, void *d_out, size_t n_bytes, 
 
 /* Measurement knobs (0 keeps the current value); they apply to plans created afterwards.
  * block / vecs: tile-kernel geometry, lanes per workgroup (128 or 256) and 4-sample groups
- *          per lane (1 or 2); the rows kernel always runs one wavefront x 2 rows.  Until a call names one,
+ *          per lane (1 or 2); the rows kernel always runs one wavefront x 2, 4 or 8 rows.  Until a call names one,
  *          every launch picks 256 x 1 or 128 x 2 (the same 1024-sample tile) from its output format and
  *          whether the plan has tile tables (measured: DESIGN.md section 4); block = vecs = -1 returns to that.
  * variant: 3 = auto: correctors tabulated wherever a period repeats at least twice; rows kernel for up to
@@ -286,6 +286,20 @@ int dpx_set_tuning(dpx_ctx *ctx, int block, int vecs, int variant);
  * fma = 1 (default): the FMA build libm selects on every x86-64 CPU with FMA+AVX2;
  * fma = 0: the SSE2 build (differs on 34 of all 2^32 arguments). */
 int dpx_set_libm_contraction(dpx_ctx *ctx, int fma);
+
+/* What `(x * 32767.0) as i16` (reference src/main.rs:77-78) means when the product leaves the i16 range — rotated full-scale
+ * samples reach sqrt(2) * 32767, and real recordings clip:
+ *   DPX_CAST_SATURATE (default): truncate toward zero, saturate to [-32768, 32767], NaN -> 0 — the language's definition
+ *       since Rust 1.45, i.e. what the reference does when built with any toolchain of the last years;
+ *   DPX_CAST_LEGACY_X86: truncate toward zero, keep the low 16 bits (40000 -> -25536); NaN and |x| >= 2^31 -> 0 — the x86-64
+ *       code a 2016 rustc (the toolchain of the reference's Cargo.lock) emitted for the then-undefined out-of-range case
+ *       (`fptosi float to i16` = CVTTSS2SI into a 32-bit register, low half stored).  For byte-for-byte comparisons with
+ *       output files produced by binaries of that time.
+ * Applies to plans created afterwards and to the host-pointer operators; plans of the legacy mode run on the tile kernel
+ * only (70-85 % of the default plans' rate).  f32 output is not affected. */
+#define DPX_CAST_SATURATE 0
+#define DPX_CAST_LEGACY_X86 1
+int dpx_set_i16_cast(dpx_ctx *ctx, int mode);
 
 /* --------------------------------------------- device memory helpers
  * For callers without their own HIP runtime binding (ctypes tests, the CLI). */

@@ -142,8 +142,23 @@ void orc_advance_samplenum(uint32_t *samplenum, float shift_hz, uint32_t sampler
 /* ------------------------------------------------------------------ A5 ---- */
 /* Rust `f32 as i16`: truncate toward zero, saturate, NaN -> 0 (defined since
  * Rust 1.45; stated as the reference's behaviour). */
+static int g_i16_cast = 0;
+/* 0: Rust >= 1.45 (`as` saturates, NaN -> 0) — the default.
+ * 1: what a 2016 rustc (the reference's Cargo.lock pins crates of that year) compiled on x86-64: `fptosi float to i16`
+ *    became CVTTSS2SI to a 32-bit register whose low half was kept — truncation toward zero, then wrap-around modulo
+ *    2^16; NaN and |x| >= 2^31 give the "integer indefinite" 0x80000000, whose low half is 0.  (LLVM called the
+ *    out-of-range case undefined; this is the instruction sequence it emitted.) */
+void orc_set_i16_cast(int mode) { g_i16_cast = mode; }
+int orc_get_i16_cast(void) { return g_i16_cast; }
+
 static inline int16_t f32_as_i16(float x)
 {
+    if (g_i16_cast == 1) {
+        int32_t w;
+        if (x != x || x >= 2147483648.0f || x < -2147483648.0f) w = INT32_MIN;    /* CVTTSS2SI: integer indefinite */
+        else w = (int32_t)x;                                                          /* truncates toward zero */
+        return (int16_t)(uint16_t)((uint32_t)w & 0xffffu);
+    }
     if (x != x) return 0;
     if (x >= 32767.0f) return 32767;
     if (x <= -32768.0f) return -32768;

@@ -50,6 +50,9 @@ void orc_set_ccexpf(orc_ccexpf_fn fn);        /* NULL restores orc_ccexpf */
 /* 0: libm cexpf (default, or oracle/_ref's ccexpf once set);
  * 1: restated glibc sincosf, FMA variant; 2: restated, non-FMA variant */
 void orc_set_corrector_mode(int mode);
+/* `as i16` of main.rs:77-78: 0 = saturating, NaN -> 0 (Rust >= 1.45, default); 1 = CVTTSS2SI + low 16 bits (x86-64 code of a 2016 rustc) */
+void orc_set_i16_cast(int mode);
+int orc_get_i16_cast(void);
 int orc_get_corrector_mode(void);
 
 /* corrector for an array of angles: out[k] = ccexpf(0 + i*theta[k]) under `mode`

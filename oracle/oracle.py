@@ -98,6 +98,12 @@ def set_corrector_mode(mode):
     lib.orc_set_corrector_mode(int(mode))
 
 
+def set_i16_cast(mode):
+    """`(x * 32767.0) as i16` of main.rs:77-78: 0 = saturating with NaN -> 0 (Rust >= 1.45, default);
+    1 = truncate, keep the low 16 bits (CVTTSS2SI, what a 2016 rustc emitted on x86-64)."""
+    lib.orc_set_i16_cast(int(mode))
+
+
 def libm_variant():
     return int(lib.orc_detect_libm_variant())
 

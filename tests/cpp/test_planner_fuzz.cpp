@@ -98,6 +98,26 @@ int main(int argc, char **argv)
             checked += (long)plan.n_samples;
         }
     }
+    {
+        // the period cache stays bounded however many distinct ratios a long-lived context sees (live track mode: one per block),
+        // and an emptied cache gives the same periods again
+        dpx::PeriodCache cache;
+        uint32_t first = 0;
+        for (uint32_t k = 0; k < 3 * (uint32_t)dpx::PeriodCache::kMaxEntries; ++k) {
+            const float ratio = dpx::ratio_of(1000.0f + 0.25f * (float)k, 1024000);
+            const uint32_t p = cache.period(ratio, 4096);
+            if (k == 0) first = p;
+            if (cache.first_reset.size() > dpx::PeriodCache::kMaxEntries) { fprintf(stderr, "period cache grew to %zu entries\n", cache.first_reset.size()); return 1; }
+        }
+        if (cache.period(dpx::ratio_of(1000.0f, 1024000), 4096) != first) { fprintf(stderr, "period changed after the cache was emptied\n"); return 1; }
+        std::vector<float> ratios;
+        std::vector<uint64_t> counts;
+        for (uint32_t k = 0; k < 5000; ++k) { ratios.push_back(dpx::ratio_of(-7000.0f + 1.5f * (float)k, 1024000)); counts.push_back(1024000); }
+        cache.prefetch(ratios.data(), counts.data(), ratios.size());
+        dpx::PeriodCache serial;
+        for (uint32_t k = 0; k < 5000; k += 97)
+            if (cache.period(ratios[k], counts[k] + 1) != serial.period(ratios[k], counts[k] + 1)) { fprintf(stderr, "prefetched period differs\n"); return 1; }
+    }
     printf("planner fuzz: %d cases x 4 kernel choices, %ld samples checked, ok\n", cases, checked);
     return 0;
 }

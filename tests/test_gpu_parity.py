@@ -864,3 +864,59 @@ def test_stream_ring_over_several_contexts(ctx, orc):
     finally:
         for c in others:
             c.close()
+
+
+def test_legacy_i16_cast_wraps_like_a_2016_rustc(ctx, orc):
+    """dpx_set_i16_cast(DPX_CAST_LEGACY_X86): `(x * 32767.0) as i16` as the x86-64 code of a 2016 rustc computed it
+    (CVTTSS2SI, low 16 bits kept: clipping samples wrap; NaN and |x| >= 2^31 give 0) against the oracle's twin
+    (orc.set_i16_cast(1), itself cross-checked by tests/test_restatement.py) — block-wise operator, bulk plans (const and
+    track-shaped, which the legacy mode confines to the tile kernel), the pack operator; and back to saturation."""
+    import doppler_amd
+    from doppler_amd import dsp
+    rng = np.random.default_rng(99)
+    n = 3 * 2048 + 77 + (1 << 16)
+    xi = make_iq("i16", n, 777, full_scale=True)                      # rotated full-scale samples clip
+    f = make_iq("f32", n, 778).view(np.float32).copy()
+    f[: n // 2] *= rng.choice([1.5, 3.0, 70.0, 7e4, 3e9, 1e30], size=n // 2).astype(np.float32)
+    f[5:13] = [np.inf, -np.inf, np.nan, 65536.0, -65536.0, 2147483648.0 / 32767, -2147483648.0 / 32767, 1e-40]
+    xf = f.view(np.uint8)
+    segs = [(20000 + 17 * k, 333.0 + 7 * k) for k in range(3)] + [(n - 3 * 20000 - 51, -4000.0)]
+    try:
+        for legacy in (1, 0):
+            ctx.set_i16_cast(bool(legacy))
+            orc.set_i16_cast(legacy)
+            differs = False
+            for intype, x in (("i16", xi), ("f32", xf)):
+                # block-wise, as main.rs:113-118 calls the closure
+                sn, sn_w, pos = 0, 0, 0
+                while pos < 3 * 8192:
+                    blk = x[pos:pos + 8192]
+                    got, _, sn = dsp.shift_block(blk, intype, "i16", sn, 5000.0, 1024000, ctx=ctx)
+                    want, _, _, sn_w = orc.shift_block(blk, intype, "i16", sn_w, 5000.0, 1024000)
+                    assert sn == sn_w
+                    assert_same_bytes(got, want, "i16", "legacy=%d block-wise %s->i16" % (legacy, intype))
+                    pos += 8192
+                # bulk: const (rows kernel by default; tile kernel in the legacy mode) and a track-shaped plan
+                want, sn_w = orc.const_stream(x, intype, "i16", 5000, 1024000)
+                got, fin = run_bulk(ctx, x, intype, "i16", [(n, 5000.0)], 1024000)
+                assert fin == sn_w
+                assert_same_bytes(got, want, "i16", "legacy=%d const bulk %s->i16" % (legacy, intype))
+                want, sn_w = orc.segments_stream(x, intype, "i16", segs, 48000)
+                got, fin = run_bulk(ctx, x, intype, "i16", segs, 48000)
+                assert fin == sn_w
+                assert_same_bytes(got, want, "i16", "legacy=%d segments %s->i16" % (legacy, intype))
+                orc.set_i16_cast(0)
+                sat, _ = orc.segments_stream(x, intype, "i16", segs, 48000)
+                orc.set_i16_cast(legacy)
+                differs = differs or not np.array_equal(sat, want)
+            assert differs == bool(legacy)                            # the inputs do exercise the corner
+            lay = doppler_amd.plan_layout([(n, 5000.0)], 1024000)
+            assert lay["rows_launches"] == 1                          # (the layout query is the default plan either way)
+            # the un-fused pack operator
+            z = np.zeros(16, dtype=orc.complex32)
+            z["re"][:8] = [1.2, -1.3, 0.5, 70000.0 / 32767, np.nan, np.inf, -np.inf, 3e9]
+            z["im"][:8] = [-1.2, 1.3, -0.5, -70000.0 / 32767, 0.0, 1.0, -1.0, -3e9]
+            assert_same_bytes(dsp.pack_iqi16(z, ctx=ctx), orc.pack_i16(z), "i16", "legacy=%d pack operator" % legacy)
+    finally:
+        ctx.set_i16_cast(False)
+        orc.set_i16_cast(0)

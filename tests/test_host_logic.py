@@ -260,3 +260,48 @@ def test_random_plans_against_sequential_rule(orc):
         assert writes_ok(w, segs, rate, sn0, block, vecs, variant), (case, segs, rate, sn0, variant)
         assert np.array_equal(c, want), (case, segs, rate, sn0, variant, int(np.flatnonzero(c != want)[0]))
         assert doppler_amd.plan_describe(segs, rate, sn0)[1] == sn_end
+
+
+def test_every_wavefront_of_a_workgroup_reaches_its_barrier(tmp_path):
+    """The two kernels with a workgroup barrier (span kernel, walk kernel) must not let a wavefront end before it: rounds 1
+    and 2 did (s_barrier only counts live wavefronts on gfx950 — hardware behaviour, not a language guarantee).  Pinned
+    twice: (1) in the source, no `return` stands between the entry of span_body / walk_rows and their __syncthreads();
+    (2) in the shipped code object (disassembled with llvm-objdump), every span_kernel instantiation holds exactly one
+    s_barrier and every walk_kernel instantiation one per rows-per-wavefront variant — if a compiler change duplicates,
+    drops or moves barriers into divergent paths, this fails here instead of hanging on the GPU; kernels without LDS
+    sharing hold none."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "doppler_amd", "csrc", "dpx_kernels.hip")).read()
+    for fn in ("span_body", "walk_rows"):
+        m = re.search(r"__device__ __forceinline__ void %s\(" % fn, src)
+        assert m, fn
+        body = src[m.end():]
+        upto = body.index("__syncthreads();")
+        code = re.sub(r"//[^\n]*", "", body[:upto])
+        assert not re.search(r"\breturn\b", code), "%s: a wavefront may leave before the workgroup barrier" % fn
+        assert body.count("__syncthreads();", 0, body.index("\n}\n")) == 1, fn
+    assert "#error" in src and "__gfx950__" in src
+    llvm = "/opt/rocm/lib/llvm/bin"
+    lib = os.path.join(root, "doppler_amd", "lib", "libdoppler_hip.so")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.check_call([llvm + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, lib, str(tmp_path / "unused.so")])
+    subprocess.check_call([llvm + "/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat,
+                           "--output=" + co, "--unbundle"])
+    dis = subprocess.run([llvm + "/llvm-objdump", "-d", co], capture_output=True, text=True, check=True).stdout
+    counts, name = {}, None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            name = m.group(1)
+            counts[name] = 0
+        elif name and "s_barrier" in line:
+            counts[name] += 1
+    kern = {k: v for k, v in counts.items() if k.startswith("_ZN3dpx")}
+    span = {k: v for k, v in kern.items() if "span_kernel" in k}
+    walk = {k: v for k, v in kern.items() if "walk_kernel" in k}
+    assert len(span) >= 32 and len(walk) >= 32, (len(span), len(walk))      # 4 format pairs x 2 libm builds x shapes
+    assert all(v == 1 for v in span.values()), {k: v for k, v in span.items() if v != 1}
+    assert all(v == 4 for v in walk.values()), {k[:60]: v for k, v in walk.items() if v != 4}
+    assert all(v == 0 for k, v in kern.items() if k not in span and k not in walk), {k[:60]: v for k, v in kern.items() if v and k not in span and k not in walk}
