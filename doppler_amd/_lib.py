@@ -34,6 +34,11 @@ class Layout(C.Structure):
                 ("leftover_ranges", C.c_uint32), ("leftover_workgroups", C.c_uint32)]
 
 
+class StreamStats(C.Structure):
+    _fields_ = [("slabs", C.c_uint64), ("plans_reused", C.c_uint64), ("plan_us", C.c_double), ("upload_us", C.c_double),
+                ("enqueue_us", C.c_double), ("total_us", C.c_double)]
+
+
 class Options(C.Structure):
     _fields_ = [("rows_mult", C.c_uint32), ("rows_maxl", C.c_uint32), ("rows_r", C.c_uint32), ("walk_waves", C.c_uint32),
                 ("walk_rows", C.c_uint32), ("walk_compute", C.c_int32), ("walk_table_rows", C.c_uint32), ("rows_compute", C.c_uint32),
@@ -99,6 +104,7 @@ _SIGNATURES = {
     "dpx_stream_next": (_i, [_vp, _P(_vp), _P(_sz)]),
     "dpx_stream_release": (_i, [_vp]),
     "dpx_stream_samplenum": (_i, [_vp, _P(_u32)]),
+    "dpx_stream_get_stats": (_i, [_vp, _vp]),
     "dpx_stream_destroy": (None, [_vp]),
     "dpx_run_device": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "dpx_debug_copy": (_i, [_vp, _vp, _vp, _sz, _vp]),

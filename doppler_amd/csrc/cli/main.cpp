@@ -670,6 +670,11 @@ int main(int argc, char **argv)
         fprintf(stderr, "doppler stats: %llu samples in %.6f s = %.1f Msamples/s (stdin -> stdout, start-up excluded; %u GPU(s), %d slabs of %zu bytes, %s in, %s out)\n",
                 (unsigned long long)total_samples, dt, total_samples / dt / 1e6, n_gpus, n_slabs, slab_bytes,
                 in_file ? "pread workers" : "one reader", out_map ? "mapped-file workers" : out_file ? "pwrite workers" : "one writer");
+        dpx_stream_stats st;
+        if (dpx_stream_get_stats(stream, &st) == DPX_OK && st.slabs)
+            fprintf(stderr, "doppler stats: dpx_stream_submit %.1f us per slab over %llu slabs (plan %.1f, device image %.1f, enqueue %.1f; %llu plans reused)\n",
+                    st.total_us / st.slabs, (unsigned long long)st.slabs, st.plan_us / st.slabs, st.upload_us / st.slabs,
+                    st.enqueue_us / st.slabs, (unsigned long long)st.plans_reused);
     }
     (void)obs;
     dpx_stream_destroy(stream);

@@ -63,6 +63,13 @@ struct PlanTuning {
     uint32_t walk_table_rows = 0;  // that threshold (0 = the planner's default)
     uint32_t walk_span = 0;      // span kernel: most rows per span (0 = the planner's default, kSpanRows); 1 = the walk kernel's
                                  // chunks of waves x rows instead (round 2's shape; also taken whenever a matrix gets a table)
+    bool operator==(const PlanTuning &o) const
+    {
+        return rows_mult == o.rows_mult && rows_maxl == o.rows_maxl && rows_r == o.rows_r && walk_waves == o.walk_waves &&
+               walk_rows == o.walk_rows && rows_compute == o.rows_compute && walk_tilemin == o.walk_tilemin &&
+               walk_compute == o.walk_compute && walk_table_rows == o.walk_table_rows && walk_span == o.walk_span &&
+               walk_flags == o.walk_flags;
+    }
     uint32_t walk_flags = 0;     // bit 0: a one-matrix span launch reads descriptors like any other (measurement of what the
                                  // descriptor load costs)
 };

@@ -212,6 +212,12 @@ class Stream:
         check(self._lib.dpx_stream_samplenum(self._h, C.byref(n)))
         return n.value
 
+    def stats(self):
+        """Host cost of submit() so far (dpx_stream_stats): slabs, plans_reused, and microseconds by part."""
+        st = _lib.StreamStats()
+        check(self._lib.dpx_stream_get_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in _lib.StreamStats._fields_}
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.dpx_stream_destroy(self._h)

@@ -262,6 +262,14 @@ int dpx_stream_pending(const dpx_stream *s, int *n_in_flight);
 int dpx_stream_next(dpx_stream *s, const void **pinned_out, size_t *out_bytes);
 int dpx_stream_release(dpx_stream *s);
 int dpx_stream_samplenum(const dpx_stream *s, uint32_t *samplenum);   /* counter after everything submitted */
+/* Host time dpx_stream_submit has spent so far, by part (microseconds, summed over `slabs` calls): planning (stretch list +
+ * launch layout; skipped when the slab buffer's resident plan was made from the same segments at the same counter:
+ * `plans_reused`), building and uploading the plan's device image, and enqueueing the two copies, the launch and the event. */
+typedef struct dpx_stream_stats {
+    uint64_t slabs, plans_reused;
+    double plan_us, upload_us, enqueue_us, total_us;
+} dpx_stream_stats;
+int dpx_stream_get_stats(const dpx_stream *s, dpx_stream_stats *out);
 void dpx_stream_destroy(dpx_stream *s);
 
 /* Same access pattern, no arithmetic: 16-byte non-temporal copy of n_bytes.

@@ -164,7 +164,7 @@ def run_cli_files(args, data, env=None, out_mode="file"):
     return r, np.frombuffer(out, dtype=np.uint8)
 
 
-@pytest.mark.parametrize("gpus", [1, 2, 3])
+@pytest.mark.parametrize("gpus", [1, 2, 3, 8])
 def test_files_in_and_out_and_several_gpus(orc, gpus):
     """Regular files on stdin / stdout take the parallel path (slabs filled with pread and drained with pwrite by worker
     threads, out of order, at the offsets of the sequential loop); --gpus N deals the slabs round-robin over N contexts
@@ -242,7 +242,7 @@ def test_status_lines_have_the_reference_format_and_cadence(orc):
         os.unlink(path)
     assert r.returncode == 0, r.stderr[-400:]
     text = r.stderr.decode("utf-8")
-    fern = re.compile(r"^\d{4}-\d\d-\d\dT\d\d:\d\d:\d\d\.[ \d]{3} \[INFO   doppler {24} +\d+\]  ")
+    fern = re.compile(r"^\d{4}-\d\d-\d\dT\d\d:\d\d:\d\d\.[ \d]{3} \[INFO   doppler {24}[ \d]{2}\d\]  ")     # {:<30} module, {:>3} call-site line
     lines = [ln for ln in text.split("\n") if ln.strip()]
     starts = [ln for ln in lines if fern.match(ln)]
     # messages with embedded newlines (the reference's "\n\n" banners) continue on unprefixed EMPTY lines only
@@ -294,3 +294,35 @@ def test_write_error_ends_with_the_status_of_a_panic():
         r = subprocess.run([EXE, "const", "-s", "1024000", "-i", "i16", "--shift", "5000"], input=bytes(x), stdout=full,
                            stderr=subprocess.PIPE, timeout=120, env=dict(os.environ, DOPPLER_SLAB_BYTES="65536"))
     assert r.returncode == 101 and b"stdout.write error" in r.stderr, (r.returncode, r.stderr[-300:])
+
+
+def test_slab_plans_are_reused_and_the_legacy_cast_is_selectable(orc):
+    """A slab buffer whose next slab has the same segments from the same counter (constant shift, period divides the slab)
+    keeps its plan and device image: the stats line counts the reuses, the bytes are the oracle's.  DOPPLER_I16_CAST=legacy
+    selects the 2016 meaning of `as i16` (clipping samples wrap): the oracle's twin, and different bytes."""
+    import re
+    rate = 1024000
+    n = 2048 * 8 * 37 + 2048 * 3 + 5          # 37 slabs of 64 KiB, three more blocks and a ragged tail of whole samples
+    x = make_iq("i16", n, 31, full_scale=True)
+    args = ["const", "-s", str(rate), "-i", "i16", "--shift", "5000"]
+    want, _ = orc.const_stream(x, "i16", "i16", 5000, rate, threads=4)
+    for gpus in (1, 3):
+        env = {"DOPPLER_DEVICES": ",".join(["0"] * gpus), "DOPPLER_SLAB_BYTES": "65536", "DOPPLER_STATS": "1"}
+        r, got = run_cli_files(args + ["--gpus", str(gpus)], x, env)
+        assert r.returncode == 0, r.stderr[-600:]
+        assert_same_bytes(got, want, "i16", "plan reuse, %d contexts" % gpus)
+        m = re.search(rb"dpx_stream_submit ([0-9.]+) us per slab over (\d+) slabs .* (\d+) plans reused", r.stderr)
+        assert m, r.stderr[-600:]
+        # every slab buffer of the ring plans once (its first slab) and reuses afterwards
+        assert int(m.group(2)) >= 38 and 5 <= int(m.group(3)) < int(m.group(2)), m.group(0)
+    orc.set_i16_cast(1)
+    try:
+        want_legacy, _ = orc.const_stream(x, "i16", "i16", 5000, rate, threads=4)
+    finally:
+        orc.set_i16_cast(0)
+    assert not np.array_equal(want_legacy, want)
+    r, got = run_cli_files(args, x, {"DOPPLER_I16_CAST": "legacy", "DOPPLER_SLAB_BYTES": "65536"})
+    assert r.returncode == 0, r.stderr[-600:]
+    assert_same_bytes(got, want_legacy, "i16", "DOPPLER_I16_CAST=legacy")
+    r, _ = run_cli_files(args, x[:8192], {"DOPPLER_I16_CAST": "sometimes"})
+    assert r.returncode == 1 and b"DOPPLER_I16_CAST" in r.stderr
