@@ -29,6 +29,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/time.h>
+#include <sys/uio.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -119,6 +120,24 @@ ssize_t gather(int fd, char *buf, size_t cap, bool *eof)
     return (ssize_t)n;
 }
 
+// A pipe on stdin / stdout is given the largest buffer the system allows (default 64 KiB: a context switch per 16 Ki
+// samples; with 1 MiB and more the reader and the writer move megabytes per system call).  Returns the size in effect.
+long grow_pipe(int fd)
+{
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISFIFO(st.st_mode)) return 0;
+    long cap = 1 << 20;
+    if (FILE *f = fopen("/proc/sys/fs/pipe-max-size", "r")) {
+        long v = 0;
+        if (fscanf(f, "%ld", &v) == 1 && v > 0) cap = v;
+        fclose(f);
+    }
+    // a privileged process may go beyond pipe-max-size: try 16 MiB first, then the limit, then halves of it
+    for (long want : {16L << 20, cap, cap / 2, cap / 4})
+        if (want >= (64 << 10) && fcntl(fd, F_SETPIPE_SZ, (int)want) >= 0) break;
+    return fcntl(fd, F_GETPIPE_SZ);
+}
+
 bool pread_all(int fd, char *buf, size_t n, off_t off)
 {
     while (n) {
@@ -149,6 +168,63 @@ bool write_all(int fd, const char *p, size_t n, bool positioned, off_t off)
     }
     return true;
 }
+
+// Output into a pipe without write()'s page allocation and kernel copy: the bytes are copied (in user space) into a
+// staging ring of ordinary pages, which vmsplice() then lends to the pipe.  A lent page may be reused once the reader has
+// taken it; the pipe holds at most `slots` pages, every piece starts on a page of its own, so a page that lies more than
+// `slots` pages behind the write position has left the pipe — the ring is four times that long.  (The pinned output slab
+// itself is never lent: it is recycled at once, and its pages belong to the GPU runtime.)
+class PipeLender {
+public:
+    bool open(int fd, long pipe_bytes)
+    {
+        page_ = (size_t)sysconf(_SC_PAGESIZE);
+        slots_ = (size_t)pipe_bytes / page_;
+        if (slots_ < 16) return false;
+        pages_ = 4 * slots_;
+        void *m = mmap(nullptr, pages_ * page_, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) return false;
+        ring_ = static_cast<char *>(m);
+        memset(ring_, 0, pages_ * page_);             // touch: the first lending pass should not page-fault
+        fd_ = fd;
+        return true;
+    }
+    ~PipeLender() { if (ring_) (void)munmap(ring_, pages_ * page_); }
+    bool active() const { return ring_ != nullptr; }
+    // false: the write failed (errno set); *unsupported: vmsplice is not available here, nothing was written
+    bool write(const char *p, size_t n, bool *unsupported)
+    {
+        *unsupported = false;
+        while (n) {
+            const size_t piece_pages = std::min(slots_, (n + page_ - 1) / page_);
+            if (pos_ + piece_pages > pages_) pos_ = 0;                  // pieces do not wrap around the ring
+            const size_t bytes = std::min(n, piece_pages * page_);
+            char *dst = ring_ + pos_ * page_;
+            memcpy(dst, p, bytes);
+            struct iovec iov = {dst, bytes};
+            while (iov.iov_len) {
+                const ssize_t w = vmsplice(fd_, &iov, 1, 0);
+                if (w < 0) {
+                    if (errno == EINTR) continue;
+                    if (first_ && (errno == EINVAL || errno == ENOSYS || errno == EBADF)) { *unsupported = true; return false; }
+                    return false;
+                }
+                first_ = false;
+                iov.iov_base = static_cast<char *>(iov.iov_base) + w;
+                iov.iov_len -= (size_t)w;
+            }
+            pos_ += piece_pages;
+            p += bytes;
+            n -= bytes;
+        }
+        return true;
+    }
+private:
+    int fd_ = -1;
+    char *ring_ = nullptr;
+    size_t page_ = 4096, slots_ = 0, pages_ = 0, pos_ = 0;
+    bool first_ = true;
+};
 
 // a tiny pool: jobs run on `n` threads, in any order
 class Workers {
@@ -342,7 +418,15 @@ int main(int argc, char **argv)
         const uint64_t share = (left / (uint64_t)io_threads + DPX_BUFFER_SIZE - 1) / DPX_BUFFER_SIZE * DPX_BUFFER_SIZE;
         slab_bytes = (size_t)std::min<uint64_t>(16u << 20, std::max<uint64_t>(1u << 20, share));
     }
-    const int slabs_per_gpu = in_file || out_file ? std::max(3, (2 * io_threads + (int)n_gpus - 1) / (int)n_gpus + 1) : 3;
+    // pipes (the reference's only I/O mode, main.rs:57-58): the largest pipe buffers the system gives, and a ring deep
+    // enough that the reader, the GPU and the writer each hold a slab with one to spare
+    const long pipe_in = live_track || getenv("DOPPLER_NO_PIPE_GROW") ? 0 : grow_pipe(STDIN_FILENO);
+    const long pipe_out = getenv("DOPPLER_NO_PIPE_GROW") ? 0 : grow_pipe(STDOUT_FILENO);
+    // a pipe hands over at most its buffer per read: slabs of that size (measured, profiles/r03_cli.md: 3.4 Gsamples/s with
+    // 1 MiB slabs against 2.5 with 8 MiB through two 1 MiB pipes) and a deeper ring
+    if (!in_file && !live_track && pipe_in > 0 && !getenv("DOPPLER_SLAB_BYTES"))
+        slab_bytes = std::max<size_t>(1u << 20, (size_t)pipe_in / DPX_BUFFER_SIZE * DPX_BUFFER_SIZE);
+    const int slabs_per_gpu = in_file || out_file ? std::max(3, (2 * io_threads + (int)n_gpus - 1) / (int)n_gpus + 1) : live_track ? 3 : 6;
     const int n_slabs = slabs_per_gpu * (int)n_gpus;
 
     dpx_stream *stream = nullptr;
@@ -399,6 +483,8 @@ int main(int argc, char **argv)
         if (!out_map) out_map_len = 0;
     }
 
+    PipeLender lender;
+    if (pipe_out > 0 && !getenv("DOPPLER_NO_VMSPLICE")) (void)lender.open(STDOUT_FILENO, pipe_out);
     // ---- consumer: oldest slab -> stdout.  Pipe: write here, in order.  File: hand the slab to a drain worker with
     // its offset; the recycling (dpx_stream_release, in order) happens as the oldest writes complete.
     std::thread consumer([&]() {
@@ -444,6 +530,11 @@ int main(int argc, char **argv)
             } else if (out_file) {
                 const off_t off = out_off;
                 drainers->push([=] { finish(write_all(STDOUT_FILENO, p, nbytes, true, off)); });
+            } else if (lender.active()) {
+                bool unsupported = false;
+                bool ok = lender.write(p, nbytes, &unsupported);
+                if (unsupported) ok = write_all(STDOUT_FILENO, p, nbytes, false, 0);      // (first piece: nothing was written yet)
+                finish(ok);
             } else {
                 finish(write_all(STDOUT_FILENO, p, nbytes, false, 0));
             }
@@ -559,8 +650,78 @@ int main(int argc, char **argv)
         return true;
     };
 
-    if (!in_file) {
-        // ---- pipe / terminal: one reader, whatever is available
+    if (!in_file && !live_track) {
+        // ---- pipe / terminal, not live: a reader thread does nothing but move bytes from the pipe into pinned slabs (it is
+        // the pipe's copy speed that bounds this path: one thread, ~9 GB/s), this thread schedules and submits them in
+        // order.  The reader still takes whatever complete blocks are there and never waits past a block boundary.
+        bool reader_done = false;                                           // guarded by mu
+        std::vector<char> read_failed((size_t)n_slabs, 0);
+        std::thread reader([&] {
+            bool eof = false;
+            uint64_t k = 0;
+            while (!eof && failure == 0) {
+                {   // every slab in use: wait for the oldest to be recycled
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return acquired - released < (uint64_t)n_slabs || failure != 0; });
+                    if (failure != 0) break;
+                }
+                void *buf = nullptr;
+                size_t cap = 0;
+                if (dpx_stream_acquire(stream, &buf, &cap) != DPX_OK) {
+                    fail_with(1, std::string("dpx_stream_acquire: ") + dpx_last_error());
+                    break;
+                }
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    ++acquired;
+                    io[k % io.size()].ready = false;
+                }
+                const ssize_t n = gather(STDIN_FILENO, static_cast<char *>(buf), cap, &eof);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    io[k % io.size()].filled = n < 0 ? 0 : (size_t)n;
+                    read_failed[k % io.size()] = n < 0;
+                    io[k % io.size()].ready = true;
+                }
+                cv.notify_all();
+                if (n < 0) break;
+                ++k;
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            reader_done = true;
+            cv.notify_all();
+        });
+        for (;;) {
+            size_t n = 0;
+            bool bad = false, have = false;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return (submitted < acquired && io[submitted % io.size()].ready) || (reader_done && submitted == acquired); });
+                if (submitted < acquired) {
+                    have = true;
+                    n = io[submitted % io.size()].filled;
+                    bad = read_failed[submitted % io.size()] != 0;
+                }
+            }
+            if (!have) break;                                               // the reader is done and everything it acquired went in
+            if (bad || failure != 0) {                                      // a failed read, or a failure elsewhere: hand the slab back empty
+                if (bad) fail_with(101, "doppler collect error");           // main.rs:63 expect()
+                (void)dpx_stream_submit(stream, 0, nullptr, 0);
+                std::lock_guard<std::mutex> lk(mu);
+                ++submitted;
+                cv.notify_all();
+                continue;
+            }
+            if (!submit_slab(n)) {
+                // the slab stays acquired in the ring; nothing more can be submitted in order: let the reader wind down
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return reader_done; });
+                break;
+            }
+        }
+        reader.join();
+    } else if (!in_file) {
+        // ---- live track mode: one block per slab, the orbit evaluated for every block as it arrives (main.rs:186-205)
         bool eof = false;
         while (!eof && failure == 0) {
             {   // every slab in use: wait for the oldest to be recycled
@@ -670,6 +831,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "doppler stats: %llu samples in %.6f s = %.1f Msamples/s (stdin -> stdout, start-up excluded; %u GPU(s), %d slabs of %zu bytes, %s in, %s out)\n",
                 (unsigned long long)total_samples, dt, total_samples / dt / 1e6, n_gpus, n_slabs, slab_bytes,
                 in_file ? "pread workers" : "one reader", out_map ? "mapped-file workers" : out_file ? "pwrite workers" : "one writer");
+        if (pipe_in || pipe_out) fprintf(stderr, "doppler stats: pipe buffers %ld bytes in, %ld bytes out%s\n", pipe_in, pipe_out, lender.active() ? " (output lent to the pipe with vmsplice)" : "");
         dpx_stream_stats st;
         if (dpx_stream_get_stats(stream, &st) == DPX_OK && st.slabs)
             fprintf(stderr, "doppler stats: dpx_stream_submit %.1f us per slab over %llu slabs (plan %.1f, device image %.1f, enqueue %.1f; %llu plans reused)\n",
