@@ -80,6 +80,8 @@ _SIGNATURES = {
     "dpx_pack_iqi16": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "dpx_shift_block": (_i, [_vp, _vp, _sz, _i, _vp, _sz, _i, _P(_u32), _f, _u32, _P(_sz)]),
     "dpx_shift_blocks": (_i, [_vp, _vp, _sz, _i, _vp, _sz, _i, _P(_u32), _vp, _sz, _u32, _P(_sz)]),
+    "dpx_shift_block_async": (_i, [_vp, _vp, _sz, _i, _i, _P(_u32), _f, _u32, _P(_u32)]),
+    "dpx_wait": (_i, [_vp, _u32, _vp, _sz, _P(_sz)]),
     "dpx_ccexpf": (_i, [_vp, _vp, _sz]),
     "dpx_ccexpf_imag": (_i, [_vp, _vp, _sz]),
     "dpx_find_reset": (_i, [_f, _u32, _u32, _u64, _P(_u32), _P(_i)]),

@@ -67,6 +67,15 @@ struct dpx_ctx {
     // the plan image; the kernel reads and writes it over PCIe directly, so a call is memcpy + one launch + one wait
     char *small_host = nullptr;
     char *small_dev = nullptr;
+    // dpx_shift_block_async / dpx_wait: a ring of such buffers, one per block in flight
+    static constexpr int kAsyncSlots = 4;
+    struct AsyncSlot {
+        char *host = nullptr, *dev = nullptr;
+        hipEvent_t done = nullptr;
+        uint32_t seq = 0;            // ticket of the block the slot holds (0: free)
+        size_t out_bytes = 0, n_samples = 0;
+    } async_slots[kAsyncSlots];
+    uint32_t async_next_seq = 1;
 };
 
 // device image of a plan: stretch table | hint table | corrector-table pool, one allocation
@@ -449,6 +458,10 @@ void dpx_ctx_destroy(dpx_ctx *ctx)
         delete ctx->scratch;
     }
     if (ctx->small_host) (void)hipHostFree(ctx->small_host);
+    for (dpx_ctx::AsyncSlot &a : ctx->async_slots) {
+        if (a.done) { (void)hipEventSynchronize(a.done); (void)hipEventDestroy(a.done); }
+        if (a.host) (void)hipHostFree(a.host);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -519,6 +532,77 @@ int dpx_shift_block(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt, v
     int rc = run_host(ctx, in, n, in_fmt, out, out_fmt, samplenum, shift_hz, samplerate);
     if (rc == DPX_OK && n_samples_out) *n_samples_out = n;
     return rc;
+}
+
+// ---- one block in flight while the caller reads the next (main.rs:113-118 with its read overlapped)
+int dpx_shift_block_async(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt, int out_fmt, uint32_t *samplenum,
+                          float shift_hz, uint32_t samplerate, dpx_ticket *ticket)
+{
+    if (!ctx || !samplenum || !ticket || (!in && in_bytes) || !fmt_ok(in_fmt) || !fmt_ok(out_fmt))
+        return fail(DPX_ERR_ARG, "bad argument");
+    if (in_bytes % bytes_per_sample(in_fmt) != 0)
+        return fail(DPX_ERR_BLOCK_LEN, "%zu bytes is not a whole number of %s samples", in_bytes,
+                    in_fmt == DPX_FMT_I16 ? "i16" : "f32");
+    const size_t n = in_bytes / bytes_per_sample(in_fmt);
+    if (n * 8 > kSmallCallBytes) return fail(DPX_ERR_CAPACITY, "an asynchronous block holds at most %zu samples", kSmallCallBytes / 8);
+    DPX_HIP(hipSetDevice(ctx->device));
+    const uint32_t seq = ctx->async_next_seq;
+    dpx_ctx::AsyncSlot &a = ctx->async_slots[seq % dpx_ctx::kAsyncSlots];
+    if (a.seq != 0) return fail(DPX_ERR_PLAN, "%d blocks are in flight: dpx_wait for ticket %u first", dpx_ctx::kAsyncSlots, a.seq);
+    if (!a.host) {
+        void *h = nullptr, *d = nullptr;
+        DPX_HIP(hipHostMalloc(&h, 2 * kSmallCallBytes + kSmallPlanBytes, hipHostMallocMapped));
+        hipError_t e = hipHostGetDevicePointer(&d, h, 0);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&a.done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            (void)hipHostFree(h);
+            return fail(DPX_ERR_HIP, "asynchronous block slot: %s", hipGetErrorString(e));
+        }
+        a.host = static_cast<char *>(h);
+        a.dev = static_cast<char *>(d);
+    }
+    dpx::PlanResult plan;
+    uint32_t sn = *samplenum;
+    dpx::plan_append(plan, dpx::ratio_of(shift_hz, samplerate), n, sn, 1 /* sincos per sample */, &ctx->periods);
+    a.n_samples = n;
+    a.out_bytes = n * bytes_per_sample(out_fmt);
+    if (n != 0) {
+        const dpx::LaunchGeom g = geometry(ctx);
+        dpx::finalize(plan, g.tile(), dpx::kChooseTileOnly);
+        if (plan.error) return fail(DPX_ERR_PLAN, "%s", plan.error);
+        const size_t seg_bytes = align256(plan.segs.size() * sizeof(dpx::DevSeg));
+        const size_t hint_bytes = plan.hint.size() * sizeof(uint32_t);
+        if (plan.lut_entries != 0 || seg_bytes + hint_bytes > kSmallPlanBytes) return fail(DPX_ERR_PLAN, "block plan exceeds its slot");
+        memcpy(a.host + kSmallInOff, in, in_bytes);
+        memcpy(a.host + kSmallPlanOff, plan.segs.data(), plan.segs.size() * sizeof(dpx::DevSeg));
+        memcpy(a.host + kSmallPlanOff + seg_bytes, plan.hint.data(), hint_bytes);
+        DevPlan dev;
+        dev.segs = reinterpret_cast<dpx::DevSeg *>(a.dev + kSmallPlanOff);
+        dev.hint = reinterpret_cast<uint32_t *>(a.dev + kSmallPlanOff + seg_bytes);
+        dev.lut = a.dev + kSmallPlanOff;      // never read: no tabulated stretch in this plan
+        const int rc = run_plan(plan, dev, a.dev + kSmallInOff, in_fmt, a.dev + kSmallOutOff, out_fmt, ctx->fma, g, ctx->stream);
+        if (rc != DPX_OK) return rc;
+    }
+    DPX_HIP(hipEventRecord(a.done, ctx->stream));
+    a.seq = seq;
+    ctx->async_next_seq = seq + 1 == 0 ? 1 : seq + 1;
+    *samplenum = sn;            // the counter after the block is known as soon as the block is planned
+    *ticket = seq;
+    return DPX_OK;
+}
+
+int dpx_wait(dpx_ctx *ctx, dpx_ticket ticket, void *out, size_t out_cap, size_t *n_samples_out)
+{
+    if (!ctx || ticket == 0) return fail(DPX_ERR_ARG, "bad argument");
+    dpx_ctx::AsyncSlot &a = ctx->async_slots[ticket % dpx_ctx::kAsyncSlots];
+    if (a.seq != ticket) return fail(DPX_ERR_ARG, "ticket %u is not in flight", ticket);
+    if (a.out_bytes > out_cap || (!out && a.out_bytes))
+        return fail(DPX_ERR_CAPACITY, "output needs %zu bytes, capacity %zu", a.out_bytes, out_cap);
+    DPX_HIP(hipEventSynchronize(a.done));
+    if (a.out_bytes) memcpy(out, a.host + kSmallOutOff, a.out_bytes);
+    if (n_samples_out) *n_samples_out = a.n_samples;
+    a.seq = 0;
+    return DPX_OK;
 }
 
 int dpx_shift_blocks(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt, void *out, size_t out_cap, int out_fmt,

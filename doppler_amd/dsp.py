@@ -21,7 +21,7 @@ from . import _lib
 from .engine import BYTES_PER_SAMPLE, DspError, as_bytes, check, complex32, default_context, fmt_code
 
 __all__ = ["convert_iqi16_to_complex", "convert_iqf32_to_complex", "shift_frequency", "shift_block",
-           "pack_iqi16", "ccexpf", "complex32", "DspError"]
+           "pack_iqi16", "ccexpf", "complex32", "DspError", "shift_block_async", "wait"]
 
 
 def _ctx(ctx):
@@ -81,6 +81,26 @@ def shift_block(inbytes, intype, outtype, samplenum, shift_hz, samplerate, ctx=N
     check(ctx._lib.dpx_shift_block(ctx.handle, b.ctypes.data, b.size, it, out.ctypes.data, out.size, ot,
                                    C.byref(sn), float(shift_hz), int(samplerate), C.byref(n)))
     return out[: n.value * BYTES_PER_SAMPLE[ot]], n.value, sn.value
+
+
+def shift_block_async(inbytes, intype, outtype, samplenum, shift_hz, samplerate, ctx=None):
+    """dpx_shift_block_async: enqueue one block, return (ticket, samplenum after the block) at once."""
+    ctx = _ctx(ctx)
+    b = as_bytes(inbytes)
+    sn = C.c_uint32(samplenum)
+    t = C.c_uint32()
+    check(ctx._lib.dpx_shift_block_async(ctx.handle, b.ctypes.data, b.size, fmt_code(intype), fmt_code(outtype), C.byref(sn),
+                                         float(shift_hz), int(samplerate), C.byref(t)))
+    return t.value, sn.value
+
+
+def wait(ticket, outtype, max_samples=8192, ctx=None):
+    """dpx_wait: the output bytes of the block behind `ticket`."""
+    ctx = _ctx(ctx)
+    out = np.empty(max_samples * BYTES_PER_SAMPLE[fmt_code(outtype)] + 8, dtype=np.uint8)
+    n = C.c_size_t()
+    check(ctx._lib.dpx_wait(ctx.handle, int(ticket), out.ctypes.data, out.size, C.byref(n)))
+    return out[: n.value * BYTES_PER_SAMPLE[fmt_code(outtype)]]
 
 
 def shift_blocks(inbytes, intype, outtype, samplenum, shift_hz_per_block, samplerate, ctx=None):

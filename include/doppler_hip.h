@@ -105,6 +105,19 @@ int dpx_shift_block(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt,
 int dpx_shift_blocks(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt, void *out, size_t out_cap, int out_fmt,
                      uint32_t *samplenum, const float *shift_hz, size_t n_blocks, uint32_t samplerate, size_t *n_samples_out);
 
+/* The same block, asynchronously: dpx_shift_block_async copies the block into one of four pinned, device-mapped staging
+ * buffers, enqueues the fused kernel and returns at once with a ticket; `samplenum` is already the counter after the block
+ * (it follows from the closed form, not from the kernel).  dpx_wait blocks until that block is done and copies its output
+ * out.  So the loop of main.rs:113-118 can read block k + 1 from stdin while block k is on the GPU:
+ *     dpx_shift_block_async(ctx, blk[k+1], ...&t[k+1]);  dpx_wait(ctx, t[k], out, ...);  write(out);
+ * Tickets complete in the order they were issued; at most four may be outstanding (DPX_ERR_PLAN beyond that).  Blocks of
+ * up to 8192 samples (the reference's block is 2048 / 1024).  Measured per 8 KiB block: 19.7 us synchronous, see
+ * profiles/r03_cli.md for the overlapped figure. */
+typedef uint32_t dpx_ticket;
+int dpx_shift_block_async(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt, int out_fmt, uint32_t *samplenum,
+                          float shift_hz, uint32_t samplerate, dpx_ticket *ticket);
+int dpx_wait(dpx_ctx *ctx, dpx_ticket ticket, void *out, size_t out_cap, size_t *n_samples_out);
+
 /* replaces complex.c:33-39 ccexpf(z): z[k] <- cexpf(z[k].re + i*z[k].im), in place, any argument
  * (bit-identical to glibc 2.35 cexpf, incl. the overflow / inf / nan rules of s_cexp_template.c). */
 int dpx_ccexpf(dpx_ctx *ctx, dpx_complex32 *z, size_t n);
