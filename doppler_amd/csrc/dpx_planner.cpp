@@ -366,6 +366,22 @@ WalkShape walk_shape(const PlanTuning &tn)
     return g;
 }
 
+// Row length of a walk / span matrix: a multiple of the period.  Measured (profiles/r03_walk.md, `tools/ab.py --set minl`,
+// replay classes): rows of 0.5-1.3 MB run 1-4 points faster than rows of one period of 10-100 thousand samples (fewer,
+// longer fronts in flight), so a long stretch takes the multiple that reaches kWalkRowTarget; a short one (a second of
+// stream) stops where its rows still fill one span of 8, and keeps the period itself while that gives no more than 12
+// rows (one span).  A rule that scored every multiple against the pitch bands of `tools/rowbench pitch3` (70-76 % around
+// 1 and 2 MiB between the rows of a workgroup, 80-84 % elsewhere) was tried and measured no better on the real kernels
+// (`tools/ab.py --set rowrule`): the bands of a bare copy are not the bands of rows shifted against their lines.
+uint64_t walk_row_length_target(uint64_t P, uint64_t target, uint64_t len)
+{
+    const uint64_t r = len / P;
+    uint64_t m = 1;
+    if (r > 12) m = std::min((target + P - 1) / P, (r + 7) / 8);
+    if (P * m < kWalkMinL) m = (kWalkMinL + P - 1) / P;
+    return P * m;
+}
+
 // matrix of the walk kernel for one stretch (dpx_types.h, WalkSeg); false if the stretch does not qualify
 bool walk_geometry(const DevSeg &s, WalkSeg *w, const PlanTuning &tn)
 {
@@ -374,16 +390,7 @@ bool walk_geometry(const DevSeg &s, WalkSeg *w, const PlanTuning &tn)
     const uint64_t A = (s.first + 31) & ~31ull, E = end & ~31ull;
     if (E <= A) return false;
     const uint64_t P = s.period;
-    // Row length: a multiple of the period.  Measured (profiles/r03_walk.md, `tools/ab.py --set minl`, replay classes): rows
-    // of 0.5-1 MB (128-256 Ki samples) run 1-4 points faster than rows of one period of 10-100 thousand samples (fewer, longer
-    // fronts in flight), so a long stretch takes the multiple that reaches kWalkRowTarget; a short one (a second of stream)
-    // stops where its rows still fill one span of 8, and keeps the period itself while that gives no more than 12 rows.
-    const uint64_t target = (tn.walk_flags >> 8) ? (uint64_t)(tn.walk_flags >> 8) * 1024u : kWalkRowTarget;   // measurement: bits 8.. of walk_flags
-    const uint64_t r = (E - A) / P;
-    uint64_t m = 1;
-    if (r > 12) m = std::min((target + P - 1) / P, (r + 7) / 8);
-    if (P * m < kWalkMinL) m = (kWalkMinL + P - 1) / P;
-    const uint64_t L = P * m;
+    const uint64_t L = walk_row_length_target(P, (tn.walk_flags >> 8) ? (uint64_t)(tn.walk_flags >> 8) * 1024u : kWalkRowTarget, E - A);   // (bits 8.. of walk_flags: measurement)
     if (L > kLutMaxEntries || E - A < 2 * L) return false;     // the table must be reused at least once
     const uint64_t rows = (E - A + L - 1) / L;
     const uint64_t longest = (L % 32 == 0) ? L : (L & ~31ull) + 32;   // rows start on 32-sample boundaries

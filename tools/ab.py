@@ -278,6 +278,34 @@ def cases(which):
             c.append(("track 300 s replay", lambda f: track_segs(300, f), "i16:f32", 3, dict(walk_span=span)))
         for span in (1, 8, 12, 16):
             c.append(("const 5001 Hz", lambda f: const_segs(5001), "i16:i16", 3, dict(walk_span=span)))
+    if which == "pairs":         # every format pair: walk kernel against span kernel shapes, const mode and replay
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for pair in ("i16:i16", "f32:i16", "i16:f32", "f32:f32"):
+            for o in (dict(walk_span=1), dict(), dict(walk_waves=5, walk_span=10), dict(walk_waves=8, walk_span=16), dict(walk_waves=2, walk_span=4)):
+                c.append(("const 5001 Hz", lambda f: const_segs(5001), pair, 3, o))
+            for o in (dict(walk_span=1), dict(), dict(walk_waves=5), dict(walk_waves=8), dict(walk_waves=5, walk_span=10)):
+                c.append(("track 300 s replay", lambda f: track_segs(300, f), pair, 3, o))
+    if which == "pairs2":        # f32-output pairs: fewer wavefronts per workgroup
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for pair in ("i16:f32", "f32:f32", "f32:i16"):
+            for o in (dict(), dict(walk_waves=2, walk_span=4), dict(walk_waves=2, walk_span=8), dict(walk_waves=2, walk_span=6), dict(walk_waves=4, walk_span=4), dict(walk_waves=4, walk_span=6)):
+                c.append(("const 5001 Hz", lambda f: const_segs(5001), pair, 3, o))
+            for o in (dict(), dict(walk_waves=2), dict(walk_waves=2, walk_span=4), dict(walk_waves=2, walk_span=6)):
+                c.append(("track 300 s replay", lambda f: track_segs(300, f), pair, 3, o))
+    if which == "rowrule":       # the scored row-length rule against round 3's first rule (target 256 Ki samples) and rows of one period
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for shift in (5001, 7777.77, 12345, 1234, 9999, 777):
+            for o in (dict(), dict(walk_flags=256 << 8), dict(walk_flags=8 << 8)):
+                c.append(("const %g Hz" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 3, o))
+        for pair in ("f32:i16", "i16:f32", "f32:f32"):
+            for shift in (5001, 7777.77):
+                for o in (dict(), dict(walk_flags=256 << 8)):
+                    c.append(("const %g Hz" % shift, lambda f, s=shift: const_segs(s), pair, 3, o))
+        for o in (dict(), dict(walk_flags=256 << 8), dict(walk_flags=8 << 8)):
+            c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, o))
+        for pair in ("f32:i16", "i16:f32", "f32:f32"):
+            for o in (dict(), dict(walk_flags=256 << 8)):
+                c.append(("track 300 s replay", lambda f: track_segs(300, f), pair, 3, o))
     if which == "span2":         # span kernel: wavefronts per workgroup
         c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
         for waves in (2, 4, 5, 8):
@@ -297,7 +325,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3", "pairs", "pairs2", "rowrule"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)

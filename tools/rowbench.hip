@@ -214,8 +214,22 @@ int main(int argc, char **argv)
             add("D", Lb, 5, 4, 2, 50, 48);
         }
     }
+    if (!strcmp(set, "pitch")) {
+        // E: the row pitch in fine steps (4 KiB from 1 MiB to 1.5 MiB, then coarser), 4 wavefronts x 2 rows: is there a
+        // structure in the pitch (channel / bank interleave) that a planner could aim for?
+        for (uint64_t Lb = 1024 * K; Lb < 1536 * K; Lb += 4 * K) add("E", Lb, 8, 4, 2, 0, 0);
+        for (uint64_t Lb = 256 * K; Lb < 1024 * K; Lb += 32 * K) add("E", Lb, 8, 4, 2, 0, 0);
+        for (uint64_t Lb = 1536 * K; Lb <= 4096 * K; Lb += 64 * K) add("E", Lb, 8, 4, 2, 0, 0);
+    }
+    if (!strcmp(set, "pitch3")) {       // the whole range a planner can choose from, 1 KiB steps
+        for (uint64_t Lb = 128 * K; Lb <= 2304 * K; Lb += 1 * K) add("G", Lb, 8, 4, 2, 0, 0);
+    }
+    if (!strcmp(set, "pitch2")) {
+        for (uint64_t Lb = 1024 * K; Lb < 1152 * K; Lb += 1 * K) add("F", Lb, 8, 4, 2, 0, 0);
+    }
+    const int rounds = cs.size() > 500 ? 3 : 7, reps = cs.size() > 500 ? 5 : 8;
     for (int w = 0; w < 2; ++w) for (Case &c : cs) burst(c, 3);
-    for (int r = 0; r < 7; ++r) for (Case &c : cs) c.ms.push_back(burst(c, 8));
+    for (int r = 0; r < rounds; ++r) for (Case &c : cs) c.ms.push_back(burst(c, reps));
     for (Case &c : cs) {
         std::sort(c.ms.begin(), c.ms.end());
         const double med = c.ms[c.ms.size() / 2];
