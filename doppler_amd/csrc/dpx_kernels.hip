@@ -1007,9 +1007,7 @@ __device__ __forceinline__ void span_body(const uint8_t *__restrict__ in, uint8_
         for (int u = 0; u < U; ++u) {
             if (rr + u < ws.row_end) {                           // uniform
                 const RowGeo g = row_geo(ws, rr + u);
-#ifndef DPX_EXP_NOCONT
                 if (col0 >= g.rowlen) continue;                  // the matrix's last row ends before this window
-#endif
                 if (col0 + WV::kCols <= g.rowlen) span_load_row<IN_FMT, OUT_FMT, true>(in, g, col0, lane, q[u]);
                 else                              span_load_row<IN_FMT, OUT_FMT, false>(in, g, col0, lane, q[u]);
             }
@@ -1031,14 +1029,6 @@ __device__ __forceinline__ void span_body(const uint8_t *__restrict__ in, uint8_
             const uint32_t j = tid + (uint32_t)it * THREADS;
             if (j < kEntries) {
                 uint32_t t = ub + j;
-#ifdef DPX_EXP_OLDMOD
-                if (ws.L == P) {
-                    t = ws.phase + col0 + j + P - kWalkPad;
-                    t = t >= 2u * P ? t - 2u * P : t;
-                    t = t >= P ? t - P : t;
-                    t = t >= P ? t - P : t;
-                } else
-#endif
                 if (P > kEntries) t = t >= P ? t - P : t;        // uniform: j < kEntries < P
                 else              t %= P;
                 float c, sn;
@@ -1054,9 +1044,7 @@ __device__ __forceinline__ void span_body(const uint8_t *__restrict__ in, uint8_
         for (int u = 0; u < U; ++u) {
             if (r + u < ws.row_end) {
                 const RowGeo g = row_geo(ws, r + u);
-#ifndef DPX_EXP_NOCONT
                 if (col0 >= g.rowlen) continue;
-#endif
                 uint32_t *xrow = xpose + (wave * U + u) * kWalkWindow;
                 if (col0 + WV::kCols <= g.rowlen) span_finish_row<IN_FMT, OUT_FMT, true>(out, g, col0, lane, q[u], slice, xrow);
                 else                              span_finish_row<IN_FMT, OUT_FMT, false>(out, g, col0, lane, q[u], slice, xrow);

@@ -331,10 +331,6 @@ __device__ __forceinline__ void corrector(float ratio, uint32_t n, float &c, flo
 {
     const float p = __fmul_rn(ratio, (float)n);          // u32 -> f32 rounds to nearest even
     const float theta = __fmul_rn(-6.28318530717958647692f, p);
-#ifdef DPX_EXP_NOSINCOS     // measurement builds only (tools/build_variant.sh): what the kernels cost without the sincos arithmetic
-    c = theta; s = p;
-    return;
-#endif
     sincosf_glibc<FMA>(theta, s, c);
 }
 
@@ -374,10 +370,6 @@ __device__ __forceinline__ void corrector4_f(float ratio, sc_f32x2 f01, sc_f32x2
     const sc_f32x2 p01 = f01 * r2, p23 = f23 * r2;
     const sc_f32x2 t01 = p01 * m2, t23 = p23 * m2;
     const float th[4] = {t01.x, t01.y, t23.x, t23.y};
-#ifdef DPX_EXP_NOSINCOS
-    for (int k = 0; k < 4; ++k) cs[k] = sc_f32x2{th[k], th[k]};
-    return;
-#endif
     bool all_plain = path == kPathPlain, all_large = path == kPathLarge;
     if (path == kPathAny) {
         uint32_t lo = 0xffffffffu, hi = 0;

@@ -1,18 +1,21 @@
-"""Where the 600 s replay loses: its one-second segments grouped by the number of rows of their walk matrix
-(= samples / period), each group timed as a plan of its own (same shifts, same lengths, concatenated)."""
+"""The 600 s replay's one-second segments grouped by the rows of their walk matrix, each group timed as a plan of its own
+under several option sets (JSON list of dpx_options dicts in OPTS; default: walk kernel 4x2 against span kernel 8 / 16)."""
 import calendar, json, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench, doppler_amd
 RATE = 1024000
 segs = bench.track_segments(600, RATE, "i16", calendar.timegm((2015, 1, 22, 19, 48, 0)))
-classes = {"rows<5": [], "5-9": [], "10-19": [], "20-39": [], ">=40": []}
+edges = [(0, 3), (3, 5), (5, 7), (7, 9), (9, 12), (12, 17), (17, 25), (25, 1 << 30)]
+classes = {e: [] for e in edges}
 for n, hz in segs:
     st, _ = doppler_amd.plan_describe([(n, hz)], RATE, samplenum=1)
     P = max(s["period"] for s in st)
     rows = n / P if P else 0
-    key = "rows<5" if rows < 5 else "5-9" if rows < 10 else "10-19" if rows < 20 else "20-39" if rows < 40 else ">=40"
-    classes[key].append((n, hz))
+    for e in edges:
+        if e[0] <= rows < e[1]:
+            classes[e].append((n, hz))
+shapes = [tuple(sorted(o.items())) for o in json.loads(os.environ.get("OPTS", '[{"walk_span":1,"walk_waves":4,"walk_rows":2},{"walk_span":8},{"walk_span":16}]'))]
 ctx = doppler_amd.Context(0)
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream()
@@ -20,26 +23,37 @@ built = []
 for key, sg in classes.items():
     if not sg:
         continue
-    sg = (sg * (1 + 60 // len(sg)))[:max(len(sg), 60)]          # at least 60 seconds of stream per class
-    n = sum(c for c, _ in sg)
-    plan = ctx.plan_segments(sg, RATE)
+    rep = (sg * (1 + 60 // len(sg)))[:max(len(sg), 60)]          # at least 60 seconds of stream per class
+    n = sum(c for c, _ in rep)
     x = torch.randint(-23170, 23171, (2 * n,), dtype=torch.int16, device=dev)
     out = torch.empty(2 * n, dtype=torch.int16, device=dev)
-    built.append([key, len(classes[key]), n, plan, x, out, [], doppler_amd.plan_layout(sg, RATE)])
+    for sh in shapes:
+        ctx.set_options(**dict(sh))
+        built.append(dict(key=key, nseg=len(sg), n=n, shape=sh, plan=ctx.plan_segments(rep, RATE), x=x, out=out, ms=[]))
+ctx.set_options()
 for b in built:
-    for _ in range(30):
-        b[3].run(b[4].data_ptr(), "i16", b[5].data_ptr(), "i16", st.cuda_stream)
+    for _ in range(10):
+        b["plan"].run(b["x"].data_ptr(), "i16", b["out"].data_ptr(), "i16", st.cuda_stream)
 st.synchronize()
-for _ in range(9):
+for _ in range(7):
     for b in built:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
-        for _ in range(20):
-            b[3].run(b[4].data_ptr(), "i16", b[5].data_ptr(), "i16", st.cuda_stream)
+        for _ in range(10):
+            b["plan"].run(b["x"].data_ptr(), "i16", b["out"].data_ptr(), "i16", st.cuda_stream)
         e1.record(st); st.synchronize()
-        b[6].append(e0.elapsed_time(e1) / 20)
-tot = sum(b[1] for b in built)
-for b in built:
-    med = statistics.median(b[6])
-    print(json.dumps({"class": b[0], "segments_in_replay": b[1], "share_pct": round(100 * b[1] / tot, 1), "samples_timed": b[2],
-                      "pct_peak": round(b[2] * 8 / med / 1e6 / 80, 1), "single_samples_pct": round(100 * b[7]["single_samples"] / b[2], 2)}))
+        b["ms"].append(e0.elapsed_time(e1) / 10)
+tot = sum(len(v) for v in classes.values())
+print("%-10s %6s  " % ("rows", "share") + " ".join("%6s" % ("o%d" % i) for i, s in enumerate(shapes)))
+t_def = t_best = 0.0
+for key in classes:
+    row = [b for b in built if b["key"] == key]
+    if not row:
+        continue
+    pct = {b["shape"]: b["n"] * 8 / statistics.median(b["ms"]) / 1e6 / 80 for b in row}
+    share = row[0]["nseg"] / tot
+    t_def += share / pct[shapes[0]]
+    t_best += share / max(pct.values())
+    print("%-10s %5.1f%%  " % ("%d-%s" % (key[0], key[1] - 1 if key[1] < 1 << 29 else ""), 100 * share) + " ".join("%6.1f" % pct[s] for s in shapes))
+print("options:", [dict(s) for s in shapes])
+print("replay composed from the classes: o0 everywhere %.1f %%, best per class %.1f %%" % (1 / t_def, 1 / t_best))

@@ -1,8 +1,8 @@
-"""Turn the rocprofv3 databases written by tools/profile_r02.sh into the summaries committed under profiles/.
+"""Turn the rocprofv3 databases written by tools/profile_round.sh into the summaries committed under profiles/.
 
-    python tools/summarize_r02.py /tmp/prof_r02 gpurun_out
-writes <out>/r02_rocprof_kernel_stats.md and <out>/r02_pmc_traffic.json (with the hash of the kernel sources, which
-bench.py checks before quoting any of it).
+    python tools/summarize_round.py /tmp/prof_r03 gpurun_out r03
+writes <out>/<round>_rocprof_kernel_stats.md and <out>/<round>_pmc_traffic.json (with the hash of the kernel sources,
+which bench.py checks before quoting any of it).
 """
 import glob
 import json
@@ -32,6 +32,19 @@ def kernel_stats(db_path):
     return [(short(n), c, a / 1e3, mn / 1e3, mx / 1e3, t / 1e3) for n, c, a, mn, mx, t in rows]
 
 
+def settled(db_path, pattern, after_ms=160.0):
+    """(launches, avg us, median us) of the kernel's launches that START more than after_ms after its first one"""
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select start, duration from kernels where name like ? order by start", ("%" + pattern + "%",)).fetchall()
+    if not rows:
+        return None
+    t0 = rows[0][0]
+    d = sorted(r[1] / 1e3 for r in rows if (r[0] - t0) / 1e6 > after_ms)
+    if len(d) < 5:
+        return None
+    return len(d), sum(d) / len(d), d[len(d) // 2]
+
+
 def counter(db_path, name, agg="avg"):
     """per kernel: (launches, avg value) — or the largest value (calibration: the context's 16-byte warm-up launch of the
     copy kernel must not be averaged with the 1 GiB copies)"""
@@ -43,10 +56,11 @@ def counter(db_path, name, agg="avg"):
 
 def main():
     src, out = sys.argv[1], sys.argv[2]
+    rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
     import bench
-    lines = ["# Round 2 — rocprofv3 --kernel-trace --stats and HBM-traffic counters (1x MI355X, `tools/profile_r02.sh`)", "",
-             "Commands: `python bench.py --workload const|track --steps 20 --warmup 5 --no-cpu --no-extra`; kernel sources sha "
-             "`%s`." % bench.kernel_source_sha(), ""]
+    lines = ["# Round %s — rocprofv3 --kernel-trace --stats and HBM-traffic counters (1x MI355X, `tools/profile_round.sh %s`)" % (rnd[1:].lstrip("0"), rnd), "",
+             "Commands: `python bench.py --workload const --steps 20 --warmup 5 --no-cpu --no-extra` and `--workload track --steps 300` "
+             "(kernel trace; the two PMC passes of either workload: 20 steps); kernel sources sha `%s`." % bench.kernel_source_sha(), ""]
     result = {"kernel_source_sha": bench.kernel_source_sha()}
     # calibration of the counters on a copy of known size
     cal_f = counter(db_of(os.path.join(src, "cal_fetch")), "FETCH_SIZE", "max")
@@ -58,7 +72,7 @@ def main():
         wscale = (1 << 30) / (cal_w[ck[0]][1] * 1024.0)
         lines += ["Calibration on `dpx::copy_kernel` (1 GiB read + 1 GiB written): FETCH_SIZE x %.4f, WRITE_SIZE x %.4f "
                   "(the guide's gfx950 note: FETCH_SIZE reports half the bytes of a wide streaming read)." % (fscale, wscale), ""]
-    for wl, pat, alg in (("const", "rows_kernel", 268435456 * 8), ("track", "walk_kernel", 614400000 * 8)):
+    for wl, pat, alg in (("const", "rows_kernel", 268435456 * 8), ("track", "span_kernel", 614400000 * 8)):
         stats = kernel_stats(db_of(os.path.join(src, wl + "_trace")))
         lines += ["## %s workload" % wl, "", "| kernel | calls | avg us | min us | max us | total us |", "|---|---|---|---|---|---|"]
         for n, c, a, mn, mx, t in stats[:6]:
@@ -72,6 +86,14 @@ def main():
             r["launches"] = c
             lines += ["", "Dominant kernel `%s`: average %.3f us over %d launches (warm-up included) -> %.1f GB/s algorithmic "
                       "(%d B per launch) = %.1f %% of the 8.0 TB/s HBM3E peak." % (n, a, c, alg / a / 1e3, alg, alg / a / 1e3 / 80.0)]
+            st = settled(db_of(os.path.join(src, wl + "_trace")), pat)
+            if st:
+                r["settled_launches"], r["settled_avg_us"], r["settled_median_us"] = st[0], round(st[1], 3), round(st[2], 3)
+                r["avg_launch_us_all_launches"] = r["avg_launch_us_kernel_trace"]
+                r["avg_launch_us_kernel_trace"] = round(st[1], 3)      # what bench.py quotes as frac_rocprof: the settled launches
+                lines += ["Launches that start more than 160 ms after the first one (%d of them: clocks settled, as in the bench line's "
+                          "`extra.track`): average %.3f us, median %.3f us -> %.1f %% / %.1f %%." %
+                          (st[0], st[1], st[2], alg / st[1] / 1e3 / 80.0, alg / st[2] / 1e3 / 80.0)]
         f = counter(db_of(os.path.join(src, wl + "_fetch")), "FETCH_SIZE")
         w = counter(db_of(os.path.join(src, wl + "_write")), "WRITE_SIZE")
         fk = [k for k in f if pat in k]
@@ -84,9 +106,9 @@ def main():
                       "against %.1f MiB algorithmic: ratio %.4f (reads alone against the input bytes: %.4f)." %
                       (rd / 2**20, wr / 2**20, (rd + wr) / 2**20, alg / 2**20, (rd + wr) / alg, rd / (alg / 2)), ""]
         result[wl] = r
-    with open(os.path.join(out, "r02_rocprof_kernel_stats.md"), "w") as fh:
+    with open(os.path.join(out, "%s_rocprof_kernel_stats.md" % rnd), "w") as fh:
         fh.write("\n".join(lines) + "\n")
-    with open(os.path.join(out, "r02_pmc_traffic.json"), "w") as fh:
+    with open(os.path.join(out, "%s_pmc_traffic.json" % rnd), "w") as fh:
         json.dump(result, fh, indent=1)
     print("\n".join(lines))
 

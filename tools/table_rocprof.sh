@@ -6,7 +6,7 @@
 set -u
 REPO=$PWD
 export TMPDIR=/tmp
-OUTMD=$REPO/gpurun_out/r02_table_rocprof.md
+OUTMD=$REPO/gpurun_out/${ROUND:-r03}_table_rocprof.md
 ITERS=${ITERS:-300}
 echo "| row | kernel | launches | median us | avg us | min us | GB/s (median) | % of 8 TB/s (median) | % (avg) | % (best) |" > $OUTMD
 echo "|---|---|---|---|---|---|---|---|---|---|" >> $OUTMD
