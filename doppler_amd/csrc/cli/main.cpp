@@ -469,16 +469,26 @@ int main(int argc, char **argv)
     // serialise on its inode lock (measured on tmpfs: more pwrite workers made the command slower, not faster).
     char *out_map = nullptr;
     size_t out_map_len = 0;
+    bool out_grown = false;             // this run extended the output file up front: a ragged tail trims it again
     if (in_file && out_file && out_base >= 0 && out_base % 4096 == 0 && !getenv("DOPPLER_NO_MMAP")) {
         const off_t in_pos = lseek(STDIN_FILENO, 0, SEEK_CUR);
         const uint64_t in_total = sin.st_size > (in_pos < 0 ? 0 : in_pos) ? (uint64_t)(sin.st_size - (in_pos < 0 ? 0 : in_pos)) : 0;
         out_map_len = (size_t)(in_total / ibs * obs);
-        if (out_map_len && ftruncate(STDOUT_FILENO, out_base + (off_t)out_map_len) == 0) {
+        // The blocks are ALLOCATED before the file is mapped (posix_fallocate, never a sparse ftruncate): a full disk then
+        // shows up here — the mapping is skipped and the ordered pwrite path reports the failed write as the reference's
+        // `stdout.write` does (status 101) — not as a SIGBUS inside a drain worker's memcpy.  A file that is already
+        // longer (`1<>file`: opened without O_TRUNC) keeps its length: the reference only overwrites the prefix.
+        const off_t want = out_base + (off_t)out_map_len;
+        out_grown = out_map_len != 0 && sout.st_size < want;
+        if (out_map_len && (!out_grown || posix_fallocate(STDOUT_FILENO, out_base, (off_t)out_map_len) == 0)) {
             // a shell's `> file` is write-only, and a shared mapping needs a readable descriptor: reopen the same file
             const int rw = open("/proc/self/fd/1", O_RDWR);
             void *m = mmap(nullptr, out_map_len, PROT_READ | PROT_WRITE, MAP_SHARED, rw >= 0 ? rw : STDOUT_FILENO, out_base);
             if (m != MAP_FAILED) out_map = static_cast<char *>(m);
             if (rw >= 0) close(rw);
+        } else if (out_grown) {
+            if (ftruncate(STDOUT_FILENO, sout.st_size) != 0) {}  // the allocation failed half way: back to the old length
+            out_grown = false;
         }
         if (!out_map) out_map_len = 0;
     }
@@ -542,10 +552,18 @@ int main(int argc, char **argv)
         }
         if (drainers) drainers->stop();             // all queued writes are done when this returns
         if (out_map) {
+            // write-back errors of the mapping belong to this run: report them like a failed write (main.rs:86-95)
+            if (msync(out_map, out_map_len, MS_SYNC) != 0 && failure == 0) {
+                std::lock_guard<std::mutex> lk(mu);
+                failure = 101;
+                failure_msg = std::string("doppler stdout.write error: ") + strerror(errno);
+            }
             (void)munmap(out_map, out_map_len);
-            if ((uint64_t)(out_off - out_base) < out_map_len && ftruncate(STDOUT_FILENO, out_off) != 0)   // a ragged tail produced less
-                info("doppler: cannot trim the output file: %s", strerror(errno));
         }
+        // a ragged tail (or a failure) produced less than was allocated up front: the file ends where the output does —
+        // whether the workers went through the mapping or, after a failed mmap, through pwrite
+        if (out_grown && ftruncate(STDOUT_FILENO, std::max<off_t>(out_off, sout.st_size)) != 0)
+            info("doppler: cannot trim the output file: %s", strerror(errno));
         if (out_file && failure == 0 && out_off > 0) (void)lseek(STDOUT_FILENO, out_off, SEEK_SET);
     });
 

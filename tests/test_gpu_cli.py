@@ -326,3 +326,43 @@ def test_slab_plans_are_reused_and_the_legacy_cast_is_selectable(orc):
     assert_same_bytes(got, want_legacy, "i16", "DOPPLER_I16_CAST=legacy")
     r, _ = run_cli_files(args, x[:8192], {"DOPPLER_I16_CAST": "sometimes"})
     assert r.returncode == 1 and b"DOPPLER_I16_CAST" in r.stderr
+
+
+def test_an_existing_longer_output_file_keeps_its_tail_and_a_full_disk_is_a_write_error(orc):
+    """File to file the output is allocated up front and mapped.  (1) A file opened without O_TRUNC (`1<>file`) that is
+    already longer than the output keeps its length and its tail — the reference only overwrites the prefix; a shorter one
+    is extended to exactly the output's length, ragged tail included.  (2) Where the blocks cannot be allocated (/dev/shm
+    mounted too small is not available here, so: a file size limit) the command falls back to ordered writes and ends with
+    the reference's write-error status 101 instead of dying on SIGBUS."""
+    import resource
+    rate = 1024000
+    n = 2048 * 300 + 100
+    x = make_iq("i16", n, 41)
+    want, _ = orc.const_stream(x, "i16", "i16", 5001, rate, threads=4)
+    args = ["const", "-s", str(rate), "-i", "i16", "--shift", "5001"]
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
+        src, dst = os.path.join(d, "in.iq"), os.path.join(d, "out.iq")
+        with open(src, "wb") as f:
+            f.write(bytes(x))
+        for pre in (want.size + 12345, 4096):
+            with open(dst, "wb") as f:
+                f.write(b"\x77" * pre)
+            with open(src, "rb") as fi, open(dst, "r+b") as fo:
+                r = subprocess.run([EXE] + args, stdin=fi, stdout=fo, stderr=subprocess.PIPE, timeout=300,
+                                   env=dict(os.environ, DOPPLER_SLAB_BYTES="262144", DOPPLER_STATS="1"))
+            assert r.returncode == 0 and b"mapped-file workers out" in r.stderr, r.stderr[-500:]
+            got = np.fromfile(dst, dtype=np.uint8)
+            assert got.size == max(pre, want.size)
+            assert_same_bytes(got[: want.size], want, "i16", "prefix of an existing file (%d bytes before)" % pre)
+            assert (got[want.size:] == 0x77).all()
+
+        def limit():
+            import signal
+            signal.signal(signal.SIGXFSZ, signal.SIG_IGN)       # inherited across exec: the limit shows up as EFBIG, like ENOSPC would
+            resource.setrlimit(resource.RLIMIT_FSIZE, (65536, 65536))
+        os.unlink(dst)
+        with open(src, "rb") as fi, open(dst, "wb") as fo:
+            r = subprocess.run([EXE] + args, stdin=fi, stdout=fo, stderr=subprocess.PIPE, timeout=300, preexec_fn=limit,
+                               env=dict(os.environ, DOPPLER_SLAB_BYTES="262144"))
+        assert r.returncode == 101 and b"stdout.write error" in r.stderr, (r.returncode, r.stderr[-500:])
+        assert os.path.getsize(dst) <= 65536
