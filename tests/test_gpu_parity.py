@@ -447,7 +447,9 @@ def test_span_kernel_one_matrix_launch(ctx, orc, span, flags):
     blockIdx.y (walk_flags=1: from descriptors in memory, like a track-shaped plan); odd period, a period with rows of whole
     lines, a counter carried in, head and tail as leftover blocks in the last grid rows; all format pairs."""
     import doppler_amd
-    cases = [((5001.0, 1024000), 0), ((777.0, 1024000), 12345), ((100.0, 1024000), 7)]
+    # ... and periods shorter than a slice (480, 256) down to 4, 2 and 1 (shift 0): the slice index wraps many times
+    cases = [((5001.0, 1024000), 0), ((777.0, 1024000), 12345), ((100.0, 1024000), 7), ((815000.0, 2400000), 77),
+             ((-15000.0, 256000), 0), ((64000.0, 256000), 3), ((128000.0, 256000), 1), ((0.0, 48000), 0)]
     n = (1 << 22) + 4321
     opts = dict(walk_span=span, walk_flags=flags)
     ctx.set_tuning(0, 0, 5)
