@@ -1278,15 +1278,37 @@ static int walk_t(const void *d_in, void *d_out, const DevSeg *d_segs, const voi
     if (w.span != 0) {
         constexpr uint32_t kSplit = WalkVec<IN_FMT, OUT_FMT>::kSplit;
         const bool uni = w.uni.n_spans != 0;
+        WalkUni u = w.uni;
+        uint32_t waves = w.waves;
         // one matrix: windows along x, spans along y, then the rows of the grid that hold the leftover blocks
-        const uint32_t left_rows = uni ? (w.n_left_wg + w.uni.nw8 - 1) / w.uni.nw8 : 0;
-        const dim3 ugrid(uni ? w.uni.nw8 * kSplit : 1, uni ? w.uni.n_spans + left_rows : 1);
+        const uint32_t left_rows = uni ? (w.n_left_wg + u.nw8 - 1) / u.nw8 : 0;
+        // The spans of a one-matrix launch follow from its arguments, so the LAUNCH may cut them differently for its format
+        // pair (the plan does not know the formats).  Every pair with an f32 side wants half the rows per workgroup in const
+        // mode, each under its own number of wavefronts (the ones without rows still share the slice) — spans of 4 against
+        // the plan's spans of 8, four shifts, two processes each (`tools/ab.py --set pairs3 / pairs4`, profiles/r03_walk.md):
+        //   f32 -> f32, 4 wavefronts: 82-83 % against 75-77;   f32 -> i16, 5 wavefronts: 80-83.7 against 75-77;
+        //   i16 -> f32, 2 wavefronts: 77-78.6 against 74-76 (68 under 4);   i16 -> i16 keeps 4 x 8 (spans of 4: 57-72).
+        // Track-shaped plans gain nothing measurable from it.  Not when the caller fixed a shape (w.auto_shape).
+        if (uni && w.auto_shape && (IN_FMT == DPX_FMT_F32 || OUT_FMT == DPX_FMT_F32) && u.seg.rows > kSpanWhole) {
+            const uint32_t k = (u.seg.rows + 3) / 4;
+            if (k + left_rows <= 65535u) {
+                u.n_spans = k;
+                u.base = u.seg.rows / k;
+                u.rem = u.seg.rows % k;
+                waves = OUT_FMT == DPX_FMT_I16 ? 5 : IN_FMT == DPX_FMT_F32 ? 4 : 2;
+            }
+        }
+        // The descriptors of a many-matrix launch fix the spans, not the workgroup size: f32 -> i16 (two 16-byte loads per
+        // lane per row) ran its replays 1.5-2 points faster under 8 wavefronts on two boxes (77.2 -> 78.8, 76.6 -> 78.9 %) and
+        // the same within that pair's run-to-run spread on a third; the other pairs lose under more than 4 (i16 -> f32 73.8 -> 61.4)
+        if (!uni && w.auto_shape && IN_FMT == DPX_FMT_F32 && OUT_FMT == DPX_FMT_I16) waves = 8;
+        const dim3 ugrid(uni ? u.nw8 * kSplit : 1, uni ? u.n_spans + left_rows : 1);
         if (uni && ugrid.y > 65535u) return DPX_ERR_ARG;
 #define DPX_SPAN_CASE(WW)                                                                                                              \
-        if (w.waves == WW) {                                                                                                           \
+        if (waves == WW) {                                                                                                             \
             if (uni) {                                                                                                                 \
-                if (fma) span_kernel<IN_FMT, OUT_FMT, true, WW, true><<<ugrid, WW * 64, 0, st>>>(in, out, w.uni, d_wdesc, w.n_left_wg, d_left, d_lhint, d_segs);   \
-                else     span_kernel<IN_FMT, OUT_FMT, false, WW, true><<<ugrid, WW * 64, 0, st>>>(in, out, w.uni, d_wdesc, w.n_left_wg, d_left, d_lhint, d_segs);  \
+                if (fma) span_kernel<IN_FMT, OUT_FMT, true, WW, true><<<ugrid, WW * 64, 0, st>>>(in, out, u, d_wdesc, w.n_left_wg, d_left, d_lhint, d_segs);   \
+                else     span_kernel<IN_FMT, OUT_FMT, false, WW, true><<<ugrid, WW * 64, 0, st>>>(in, out, u, d_wdesc, w.n_left_wg, d_left, d_lhint, d_segs);  \
             } else {                                                                                                                   \
                 if (fma) span_kernel<IN_FMT, OUT_FMT, true, WW, false><<<grid, WW * 64, 0, st>>>(in, out, w.uni, d_wdesc, w.n_left_wg, d_left, d_lhint, d_segs);   \
                 else     span_kernel<IN_FMT, OUT_FMT, false, WW, false><<<grid, WW * 64, 0, st>>>(in, out, w.uni, d_wdesc, w.n_left_wg, d_left, d_lhint, d_segs);  \

@@ -703,6 +703,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         ln.walk.compute_slice = 0;
         ln.walk.span = span;
         memset(&ln.walk.uni, 0, sizeof ln.walk.uni);
+        ln.walk.auto_shape = (!tn.walk_waves && !tn.walk_span) ? 1u : 0u;
         if (span && mats.size() == 1 && !(tn.walk_flags & 1u)) {      // one matrix: the kernel takes it from its arguments
             const uint32_t k = walk_chunks(mats[0], tnw);
             ln.walk.uni.seg = mats[0];

@@ -169,6 +169,7 @@ struct WalkArgs {
     uint32_t span;                   // != 0: span kernel — a descriptor is a span of up to this many rows, its workgroups loop over them
                                      // two rows per wavefront per turn (every slice evaluated); 0: walk kernel, chunks of waves x rows_per_wave
     WalkUni uni;                     // span launches of one matrix
+    uint32_t auto_shape;             // the caller named neither walk_waves nor walk_span: a one-matrix launch may cut its spans per format pair
 };
 
 struct TileArgs {

@@ -306,6 +306,30 @@ def cases(which):
         for pair in ("f32:i16", "i16:f32", "f32:f32"):
             for o in (dict(), dict(walk_flags=256 << 8)):
                 c.append(("track 300 s replay", lambda f: track_segs(300, f), pair, 3, o))
+    if which == "pairs3":        # const mode, f32 output: fewer rows and wavefronts per workgroup
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for pair in ("i16:f32", "f32:f32"):
+            for shift in (5001, 7777.77, 1234, 12345):
+                for o in (dict(), dict(walk_waves=2, walk_span=4), dict(walk_waves=2, walk_span=6), dict(walk_waves=4, walk_span=4), dict(walk_waves=4, walk_span=6)):
+                    c.append(("const %g Hz" % shift, lambda f, s=shift: const_segs(s), pair, 3, o))
+    if which == "shapes":        # every (wavefronts, rows per span) shape of the span kernel, per format pair: const mode and replay
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for pair in ("i16:i16", "f32:i16", "i16:f32", "f32:f32"):
+            c.append(("const 5001 Hz", lambda f: const_segs(5001), pair, 3, {}))
+            c.append(("track 300 s replay", lambda f: track_segs(300, f), pair, 3, {}))
+            for waves in (2, 4, 5, 8):
+                for span in (2, 4, 6, 8, 10, 12, 16):
+                    if span > 4 * waves:
+                        continue
+                    c.append(("const 5001 Hz", lambda f: const_segs(5001), pair, 3, dict(walk_waves=waves, walk_span=span)))
+                    if span >= 4:
+                        c.append(("track 300 s replay", lambda f: track_segs(300, f), pair, 3, dict(walk_waves=waves, walk_span=span)))
+    if which == "pairs4":        # const mode, f32 -> i16 and i16 -> i16: few rows, many wavefronts
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for pair in ("f32:i16", "i16:i16"):
+            for shift in (5001, 7777.77, 1234, 12345):
+                for o in (dict(), dict(walk_waves=8, walk_span=4), dict(walk_waves=5, walk_span=4), dict(walk_waves=4, walk_span=4), dict(walk_waves=8, walk_span=8), dict(walk_waves=4, walk_span=8)):
+                    c.append(("const %g Hz" % shift, lambda f, s=shift: const_segs(s), pair, 3, o))
     if which == "span2":         # span kernel: wavefronts per workgroup
         c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
         for waves in (2, 4, 5, 8):
@@ -325,7 +349,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3", "pairs", "pairs2", "rowrule"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3", "pairs", "pairs2", "rowrule", "pairs3", "shapes", "pairs4"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
