@@ -330,6 +330,11 @@ def cases(which):
             for shift in (5001, 7777.77, 1234, 12345):
                 for o in (dict(), dict(walk_waves=8, walk_span=4), dict(walk_waves=5, walk_span=4), dict(walk_waves=4, walk_span=4), dict(walk_waves=8, walk_span=8), dict(walk_waves=4, walk_span=8)):
                     c.append(("const %g Hz" % shift, lambda f, s=shift: const_segs(s), pair, 3, o))
+    if which == "tshape":        # track-shaped plans, i16 -> i16: span heights (identical plans included: the spread of the method)
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for o in (dict(), dict(walk_waves=4, walk_span=12), dict(walk_span=8), dict(walk_span=10), dict(walk_span=16), dict(), dict(walk_span=1)):
+            c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, o))
+            c.append(("track 300 s replay", lambda f: track_segs(300, f), "i16:i16", 3, o))
     if which == "span2":         # span kernel: wavefronts per workgroup
         c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
         for waves in (2, 4, 5, 8):
@@ -349,7 +354,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3", "pairs", "pairs2", "rowrule", "pairs3", "shapes", "pairs4"])
+    ap.add_argument("--shuffle", action="store_true", help="time the cases in a different order every round")
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3", "pairs", "pairs2", "rowrule", "pairs3", "shapes", "pairs4", "tshape"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
@@ -386,8 +392,13 @@ def main():
         for _ in range(3):
             b["plan"].run(x.data_ptr(), b["it"], o.data_ptr(), b["ot"], stream.cuda_stream)
     stream.synchronize()
+    import random
+    rng = random.Random(12345)
     for _ in range(args.rounds):
-        for b in built:
+        order = list(built)
+        if args.shuffle:        # a case's figure depends a little on what ran just before it (clocks, power): vary the neighbours
+            rng.shuffle(order)
+        for b in order:
             x, o = bufs[(b["it"], "in", b["n"])], bufs[(b["ot"], "out", b["n"])]
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
