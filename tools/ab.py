@@ -335,6 +335,19 @@ def cases(which):
         for o in (dict(), dict(walk_waves=4, walk_span=12), dict(walk_span=8), dict(walk_span=10), dict(walk_span=16), dict(), dict(walk_span=1)):
             c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, o))
             c.append(("track 300 s replay", lambda f: track_segs(300, f), "i16:i16", 3, o))
+    if which == "longp":         # periods of a million samples: rows kernel (correctors per wavefront) against span kernel shapes
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for shift in (3, 1, 10):
+            for pair in ("i16:i16", "f32:f32"):
+                c.append(("const %g Hz" % shift, lambda f, s=shift: const_segs(s), pair, 3, {}))
+                for o in (dict(), dict(walk_waves=4, walk_span=4), dict(walk_waves=2, walk_span=4), dict(walk_waves=4, walk_span=6), dict(walk_flags=2048 << 8), dict(walk_waves=4, walk_span=12)):
+                    c.append(("const %g Hz (walk forced)" % shift, lambda f, s=shift: const_segs(s), pair, 5, o))
+    if which == "route2":        # page-aligned periods from 2592 to a million samples: rows kernel against span kernel
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for shift in (2, 3, 4, 5, 8, 20, 25, 40, 50, 100, 200, 9876.543):
+            for pair in ("i16:i16", "f32:f32", "f32:i16"):
+                c.append(("const %g Hz" % shift, lambda f, s=shift: const_segs(s), pair, 6, {}))
+                c.append(("const %g Hz (walk forced)" % shift, lambda f, s=shift: const_segs(s), pair, 5, {}))
     if which == "span2":         # span kernel: wavefronts per workgroup
         c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
         for waves in (2, 4, 5, 8):
@@ -355,7 +368,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
     ap.add_argument("--shuffle", action="store_true", help="time the cases in a different order every round")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3", "pairs", "pairs2", "rowrule", "pairs3", "shapes", "pairs4", "tshape"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3", "pairs", "pairs2", "rowrule", "pairs3", "shapes", "pairs4", "tshape", "longp", "route2"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
