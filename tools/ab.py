@@ -348,6 +348,16 @@ def cases(which):
             for pair in ("i16:i16", "f32:f32", "f32:i16"):
                 c.append(("const %g Hz" % shift, lambda f, s=shift: const_segs(s), pair, 6, {}))
                 c.append(("const %g Hz (walk forced)" % shift, lambda f, s=shift: const_segs(s), pair, 5, {}))
+    if which == "sincos1":       # where the sincos arithmetic shows: per-sample path, replay, const walk (two builds: tools/ab_libs.sh)
+        c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
+        for shift in (3, 5001):
+            c.append(("const %d Hz, sincos per sample" % shift, lambda f, s=shift: const_segs(s), "i16:i16", 1, {}))
+            c.append(("const %d Hz, sincos per sample" % shift, lambda f, s=shift: const_segs(s), "f32:f32", 1, dict(_geom=(256, 1))))
+        c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, {}))
+        c.append(("const 5001 Hz", lambda f: const_segs(5001), "i16:i16", 3, {}))
+        c.append(("const 3 Hz", lambda f: const_segs(3), "i16:i16", 3, {}))
+        for rows in (3, 5):
+            c.append(("synth %d rows of P=65536" % rows, lambda f, r=rows: synth_segs(r, total=307200000), "i16:i16", 3, {}))
     if which == "span2":         # span kernel: wavefronts per workgroup
         c.append(("const 5000 Hz (headline)", lambda f: const_segs(5000), "i16:i16", 3, {}))
         for waves in (2, 4, 5, 8):
@@ -368,7 +378,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
     ap.add_argument("--shuffle", action="store_true", help="time the cases in a different order every round")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3", "pairs", "pairs2", "rowrule", "pairs3", "shapes", "pairs4", "tshape", "longp", "route2"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3", "pairs", "pairs2", "rowrule", "pairs3", "shapes", "pairs4", "tshape", "longp", "route2", "sincos1"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
