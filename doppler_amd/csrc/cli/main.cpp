@@ -122,10 +122,11 @@ ssize_t gather(int fd, char *buf, size_t cap, bool *eof)
 
 // A pipe on stdin / stdout is given the largest buffer the system allows (default 64 KiB: a context switch per 16 Ki
 // samples; with 1 MiB and more the reader and the writer move megabytes per system call).  Returns the size in effect.
-long grow_pipe(int fd)
+long grow_pipe(int fd, bool grow = true)
 {
     struct stat st;
     if (fstat(fd, &st) != 0 || !S_ISFIFO(st.st_mode)) return 0;
+    if (!grow) return fcntl(fd, F_GETPIPE_SZ);
     long cap = 1 << 20;
     if (FILE *f = fopen("/proc/sys/fs/pipe-max-size", "r")) {
         long v = 0;
@@ -179,23 +180,38 @@ public:
     bool open(int fd, long pipe_bytes)
     {
         page_ = (size_t)sysconf(_SC_PAGESIZE);
-        slots_ = (size_t)pipe_bytes / page_;
-        if (slots_ < 16) return false;
-        pages_ = 4 * slots_;
-        void *m = mmap(nullptr, pages_ * page_, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        fd_ = fd;
+        return resize((size_t)pipe_bytes / page_);
+    }
+    // (rings are never unmapped while the process runs: a page may still sit in the pipe; the pipe keeps it alive anyway)
+    bool resize(size_t slots)
+    {
+        if (slots < 16) return false;
+        void *m = mmap(nullptr, 4 * slots * page_, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (m == MAP_FAILED) return false;
         ring_ = static_cast<char *>(m);
+        slots_ = slots;
+        pages_ = 4 * slots;
+        pos_ = 0;
         memset(ring_, 0, pages_ * page_);             // touch: the first lending pass should not page-fault
-        fd_ = fd;
         return true;
     }
-    ~PipeLender() { if (ring_) (void)munmap(ring_, pages_ * page_); }
     bool active() const { return ring_ != nullptr; }
     // false: the write failed (errno set); *unsupported: vmsplice is not available here, nothing was written
     bool write(const char *p, size_t n, bool *unsupported)
     {
         *unsupported = false;
         while (n) {
+            // the reader may have enlarged the pipe (F_SETPIPE_SZ on its end) since the ring was sized: the reuse distance
+            // must follow the pipe's real capacity, so it is read again before every piece (a piece is at most `slots_`
+            // pages and the ring four times that, so one piece lent into a pipe that has just grown cannot wrap onto a
+            // page still queued), and a larger pipe gets a larger ring
+            const long cap = fcntl(fd_, F_GETPIPE_SZ);
+            if (cap > 0 && (size_t)cap / page_ > slots_ && !resize((size_t)cap / page_)) {
+                if (first_) { *unsupported = true; ring_ = nullptr; }      // nothing lent yet: the caller writes instead
+                errno = ENOMEM;
+                return false;
+            }
             const size_t piece_pages = std::min(slots_, (n + page_ - 1) / page_);
             if (pos_ + piece_pages > pages_) pos_ = 0;                  // pieces do not wrap around the ring
             const size_t bytes = std::min(n, piece_pages * page_);
@@ -420,8 +436,9 @@ int main(int argc, char **argv)
     }
     // pipes (the reference's only I/O mode, main.rs:57-58): the largest pipe buffers the system gives, and a ring deep
     // enough that the reader, the GPU and the writer each hold a slab with one to spare
-    const long pipe_in = live_track || getenv("DOPPLER_NO_PIPE_GROW") ? 0 : grow_pipe(STDIN_FILENO);
-    const long pipe_out = getenv("DOPPLER_NO_PIPE_GROW") ? 0 : grow_pipe(STDOUT_FILENO);
+    const bool grow = !getenv("DOPPLER_NO_PIPE_GROW");
+    const long pipe_in = live_track || !grow ? 0 : grow_pipe(STDIN_FILENO);
+    const long pipe_out = grow_pipe(STDOUT_FILENO, grow);
     // a pipe hands over at most its buffer per read: slabs of that size (measured, profiles/r03_cli.md: 3.4 Gsamples/s with
     // 1 MiB slabs against 2.5 with 8 MiB through two 1 MiB pipes) and a deeper ring
     if (!in_file && !live_track && pipe_in > 0 && !getenv("DOPPLER_SLAB_BYTES"))

@@ -3,6 +3,7 @@ reference driver loops (main.rs:102-119 const, main.rs:156-184 track replay)."""
 import ctypes as C
 import os
 import subprocess
+import sys
 import tempfile
 
 import numpy as np
@@ -366,3 +367,39 @@ def test_an_existing_longer_output_file_keeps_its_tail_and_a_full_disk_is_a_writ
                                env=dict(os.environ, DOPPLER_SLAB_BYTES="262144"))
         assert r.returncode == 101 and b"stdout.write error" in r.stderr, (r.returncode, r.stderr[-500:])
         assert os.path.getsize(dst) <= 65536
+
+
+def test_output_lent_to_a_pipe_that_the_reader_enlarges(orc):
+    """The output side lends staging pages to the pipe (vmsplice) and reuses a page only when it has provably left the pipe,
+    which depends on the pipe's capacity — and the READER may change that at any time.  Here the pipe starts at 64 KiB
+    (DOPPLER_NO_PIPE_GROW), the reader stalls, enlarges it to 1 MiB, stalls again and only then drains: the bytes must be the
+    oracle's (a ring sized for the small pipe would have been overwritten under the queued pages)."""
+    rate = 1024000
+    n = 2048 * 4000 + 123
+    x = make_iq("i16", n, 51)
+    want, _ = orc.const_stream(x, "i16", "i16", 5000, rate, threads=4)
+    reader = ("import sys, time, fcntl, os\n"
+              "time.sleep(0.3)\n"
+              "fcntl.fcntl(0, 1031, 1 << 20)\n"            # F_SETPIPE_SZ
+              "time.sleep(0.5)\n"
+              "out = open(sys.argv[1], 'wb')\n"
+              "while True:\n"
+              "    b = os.read(0, 1 << 16)\n"
+              "    if not b: break\n"
+              "    out.write(b)\n"
+              "    time.sleep(0.0005)\n")
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
+        src, dst = os.path.join(d, "in.iq"), os.path.join(d, "out.iq")
+        with open(src, "wb") as f:
+            f.write(bytes(x))
+        env = dict(os.environ, DOPPLER_NO_PIPE_GROW="1", DOPPLER_STATS="1", DOPPLER_SLAB_BYTES="262144")
+        with open(src, "rb") as fi:
+            p1 = subprocess.Popen([EXE, "const", "-s", str(rate), "-i", "i16", "--shift", "5000"], stdin=fi, stdout=subprocess.PIPE,
+                                  stderr=subprocess.PIPE, env=env)
+            p2 = subprocess.Popen([sys.executable, "-c", reader, dst], stdin=p1.stdout)
+            p1.stdout.close()
+            err = p1.stderr.read()
+            assert p2.wait(timeout=300) == 0 and p1.wait(timeout=300) == 0, err[-500:]
+        assert b"output lent to the pipe with vmsplice" in err, err[-500:]
+        got = np.fromfile(dst, dtype=np.uint8)
+    assert_same_bytes(got, want, "i16", "vmsplice output, pipe enlarged by the reader")
