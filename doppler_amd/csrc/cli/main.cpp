@@ -98,13 +98,20 @@ double wall_clock()
 
 // Reads into buf until at least one full 8192-byte block or EOF, then keeps taking what is already there (never waits
 // for more) up to `cap`.  Returns bytes read, or -1 on a read error; *eof set at end of input.
-ssize_t gather(int fd, char *buf, size_t cap, bool *eof)
+// `stop` (optional): set by another thread when the run has failed elsewhere — a reader waiting for input that may never
+// come (a pipe whose writer neither writes nor closes) gives up within a fifth of a second instead of blocking in read().
+ssize_t gather(int fd, char *buf, size_t cap, bool *eof, const std::atomic<int> *stop = nullptr)
 {
     size_t n = 0;
     while (n < cap) {
         if (n > 0 && n % DPX_BUFFER_SIZE == 0) {     // on a block boundary: take more only if it is already there
             struct pollfd p = {fd, POLLIN, 0};
             if (poll(&p, 1, 0) <= 0 || !(p.revents & (POLLIN | POLLHUP))) break;
+        } else if (stop) {
+            struct pollfd p = {fd, POLLIN, 0};
+            int pr;
+            while ((pr = poll(&p, 1, 200)) == 0 && *stop == 0) {}
+            if (pr == 0) break;                      // the run is being wound down: hand over what there is
         }
         const ssize_t r = read(fd, buf + n, cap - n);
         if (r < 0) {
@@ -711,7 +718,7 @@ int main(int argc, char **argv)
                     ++acquired;
                     io[k % io.size()].ready = false;
                 }
-                const ssize_t n = gather(STDIN_FILENO, static_cast<char *>(buf), cap, &eof);
+                const ssize_t n = gather(STDIN_FILENO, static_cast<char *>(buf), cap, &eof, &failure);
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     io[k % io.size()].filled = n < 0 ? 0 : (size_t)n;

@@ -403,3 +403,27 @@ def test_output_lent_to_a_pipe_that_the_reader_enlarges(orc):
         assert b"output lent to the pipe with vmsplice" in err, err[-500:]
         got = np.fromfile(dst, dtype=np.uint8)
     assert_same_bytes(got, want, "i16", "vmsplice output, pipe enlarged by the reader")
+
+
+def test_a_failed_write_ends_the_run_even_if_the_input_pipe_stays_open():
+    """stdout.write fails (ENOSPC from /dev/full) while stdin is a pipe whose writer neither writes more nor closes: the
+    reader thread must not sit in read() for ever — status 101 (main.rs:86-95 unwrap) within a second or two."""
+    x = make_iq("i16", 2048 * 2000, 61)
+    with open("/dev/full", "wb") as full:
+        p = subprocess.Popen([EXE, "const", "-s", "1024000", "-i", "i16", "--shift", "5000"], stdin=subprocess.PIPE, stdout=full,
+                             stderr=subprocess.PIPE)
+        try:
+            p.stdin.write(bytes(x))
+            p.stdin.flush()
+        except BrokenPipeError:
+            pass
+        try:
+            rc = p.wait(timeout=30)             # stdin is still open on our side
+        finally:
+            try:
+                p.stdin.close()
+            except BrokenPipeError:
+                pass
+            if p.poll() is None:
+                p.kill()
+    assert rc == 101 and b"stdout.write error" in p.stderr.read()
