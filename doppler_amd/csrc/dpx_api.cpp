@@ -982,9 +982,13 @@ struct SlabKey {
 static SlabKey slab_key(const dpx_ctx *ctx, const dpx::LaunchGeom &g, const dpx_segment *segs, size_t n_segs, uint32_t samplerate, uint32_t sn)
 {
     SlabKey k;
-    uint64_t h = 1469598103934665603ull;                       // FNV-1a over the segment list (the list itself is compared as well)
-    const unsigned char *p = reinterpret_cast<const unsigned char *>(segs);
-    for (size_t i = 0; i < n_segs * sizeof(dpx_segment); ++i) h = (h ^ p[i]) * 1099511628211ull;
+    uint64_t h = 1469598103934665603ull;                       // FNV-1a over the segments' fields (the list itself is compared as well)
+    for (size_t i = 0; i < n_segs; ++i) {
+        uint32_t bits;
+        memcpy(&bits, &segs[i].shift_hz, sizeof bits);
+        h = (h ^ segs[i].n_samples) * 1099511628211ull;
+        h = (h ^ bits) * 1099511628211ull;
+    }
     k.segs_hash = h;
     k.samplerate = samplerate;
     k.sn_start = sn;
@@ -1135,8 +1139,9 @@ int dpx_stream_submit(dpx_stream *s, size_t in_bytes, const dpx_segment *segs, s
     uint32_t sn = s->samplenum;
     const dpx::LaunchGeom g = geometry(ctx);
     const SlabKey key = slab_key(ctx, g, segs, n_segs, s->samplerate, sn);
-    const bool reuse = total != 0 && b.have_key && b.key == key && b.key_segs.size() == n_segs &&
-                       (n_segs == 0 || memcmp(b.key_segs.data(), segs, n_segs * sizeof(dpx_segment)) == 0);
+    bool reuse = total != 0 && b.have_key && b.key == key && b.key_segs.size() == n_segs;
+    for (size_t i = 0; reuse && i < n_segs; ++i)             // field by field: the structs have padding
+        reuse = b.key_segs[i].n_samples == segs[i].n_samples && memcmp(&b.key_segs[i].shift_hz, &segs[i].shift_hz, sizeof(float)) == 0;
     if (reuse) {
         sn = b.key_sn_after;
         ++s->stats.plans_reused;

@@ -703,7 +703,7 @@ __global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restr
     constexpr bool XP = WalkVec<IN_FMT, OUT_FMT>::kTranspose;
     typedef SlicePlanes<S, WalkVec<IN_FMT, OUT_FMT>::kEntries> SPK;
     __shared__ float2 slice[SPK::kPlanes * SPK::kStride];
-    __shared__ uint32_t xpose[XP ? WAVES * (int)kWalkMaxRowsPerWave * (int)kWalkWindow : 1];   // packed i16 samples of one row per (wavefront, u)
+    __shared__ __attribute__((aligned(16))) uint32_t xpose[XP ? WAVES * (int)kWalkMaxRowsPerWave * (int)kWalkWindow : 4];   // packed i16 samples of one row per (wavefront, u); read back as 16-byte vectors
     const uint32_t tid = threadIdx.x;
 
     // ONE scalar load before the first sample load: the descriptor of this group of 8 workgroups — a row chunk of a
@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(WAVES * 64) void span_kernel(const uint8_t *__restr
     constexpr bool XP = WalkVec<IN_FMT, OUT_FMT>::kTranspose;
     typedef SlicePlanes<S, WalkVec<IN_FMT, OUT_FMT>::kEntries> SPK;
     __shared__ float2 slice[SPK::kPlanes * SPK::kStride];
-    __shared__ uint32_t xpose[XP ? WAVES * kSpanU * (int)kWalkWindow : 1];   // packed i16 samples of one row per (wavefront, u)
+    __shared__ __attribute__((aligned(16))) uint32_t xpose[XP ? WAVES * kSpanU * (int)kWalkWindow : 4];   // packed i16 samples of one row per (wavefront, u); read back as 16-byte vectors
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t kSplit = WalkVec<IN_FMT, OUT_FMT>::kSplit;
     const uint32_t half = blockIdx.x % kSplit;
