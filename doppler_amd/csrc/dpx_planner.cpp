@@ -195,7 +195,7 @@ static void emit(PlanResult &plan, uint64_t first, uint64_t count, float ratio, 
     } else {
         s.n_plain = first_counter_reaching(ratio, 0x39800000u);     // 2^-12
         s.n_large = first_counter_reaching(ratio, 0x42f00000u);     // 120
-        s.n_huge = first_counter_reaching(ratio, 0x50000000u);      // 2^33
+        s.n_huge = first_counter_reaching(ratio, 0x4e800000u);      // 2^30 (dpx_sincos.h, kLargeQuickEnd)
     }
     s.pad = 0;
     s.first = first;

@@ -26,17 +26,20 @@
 // four cycles per wavefront, f64 included (measured, profiles/r02_valubench.md), so
 // the function is priced in instructions:
 //   * fast path, taken when EVERY active lane has 2^-12 <= |y| < 120 (one ballot,
-//     a wave-uniform branch): quadrant reduction + the two polynomials and nothing
-//     else — no range selects, no clamps (31 instructions);
+//     a wave-uniform branch): quadrant reduction (4 instructions: the rounding is a
+//     fused multiply-add against 1.5 * 2^52) + the two polynomials and nothing
+//     else — no range selects, no clamps;
+//   * every active lane in [120, 2^30) — all a stream produces beyond 120, since
+//     |theta| < 2^26: the remainder of x * 2/pi from a three-term 2/pi in double
+//     precision (7 instructions; rounds 1-3: glibc's 32x96-bit integer product,
+//     31 instructions).  Not glibc's operation sequence — its RESULT, proved over
+//     the whole range by enumeration (reduce_large_quick below);
 //   * general path otherwise.  |y| < 2^-12 ("tiny") and inf/nan are per-lane
 //     selects; the "< pi/4" range goes through the quadrant-reduction formula,
 //     which yields quadrant 0 and an unchanged argument there (n*hpi = 0), so it
 //     is exactly the direct polynomial; |y| >= 120 uses the 32x96-bit fixed-point
 //     product with 4/pi, whose three 32-bit windows are cut out of the bit string
-//     with 64-bit register shifts (no memory access: a table load in the middle
-//     of the function would queue behind the kernel's sample loads — vmcnt is
-//     in-order — and serialise the arithmetic behind HBM latency).  Only
-//     |y| >= 2^33, which no stream produces (|theta| < 2^26), reads the table.
+//     with 64-bit register shifts, or read from the table for |y| >= 2^33.
 // The two polynomial tables of glibc (cos / -cos) and the sign[] table are
 // replaced by exact sign flips of the results (round-to-nearest is symmetric).
 #pragma once
@@ -66,19 +69,53 @@ __device__ __forceinline__ double mad(double a, double b, double c)
     }
 }
 
-// quadrant reduction for |x| < 120 (glibc: ranges "< pi/4" and "< 120"):
-// n = round(x * 2/pi) via a scaled truncating conversion, xr = x - n*pi/2
+// quadrant reduction for |x| < 120 (glibc: ranges "< pi/4" and "< 120"): n = round(x * 2/pi), xr = x - n*pi/2.
+//
+// glibc rounds with a scaled truncating conversion, n = ((int32)(x * 2/pi * 2^24) + 2^23) >> 24.  Here (round 4) the
+// rounding is ONE fused multiply-add against 1.5 * 2^52: the sum's low mantissa word IS n (two's complement), the double
+// n comes back with one subtraction — four instructions instead of seven, no conversion.  The two roundings agree for
+// every float below 120 except five negative arguments within 2^-24 of a quadrant boundary (glibc truncates toward zero
+// before adding the half, so it rounds those ties-by-truncation toward +inf: -0x1.921fb6p-1, -0x1.921fb8p-1,
+// -0x1.2d97c8p+1, -0x1.c463acp+2, -0x1.78fdbap+3), where the neighbouring quadrant with the mirrored remainder gives the
+// same two floats.  That is a finite statement and it is checked, not argued: all 2^32 arguments, both libm builds, on
+// the CPU model (tools/sincos_model.c) and on the device (tests/extended/exhaustive_device_sincos.py): 0 mismatches.
+constexpr double kTwoOverPi = 0x1.45F306DC9C883p-1;        // 2/pi rounded to double: glibc's hpi_inv / 2^24
+constexpr double kRoundMagic = 0x1.8p52;                   // 1.5 * 2^52: ulp 1, room for |n| < 2^31
+constexpr uint32_t kLargeQuickEnd = 0x4e800000u;           // 2^30: where reduce_large_quick's proof ends (DevSeg::n_huge)
 template <bool FMA>
 __device__ __forceinline__ double reduce_small(double x, uint32_t &n_out)
 {
-    constexpr double HPI_INV = 0x1.45F306DC9C883p+23;   // 2/pi * 2^24
     constexpr double HPI = 0x1.921FB54442D18p0;         // pi/2
-    const double r = x * HPI_INV;
-    const int n = (__double2int_rz(r) + 0x800000) >> 24;
-    const double nd = (double)n;
-    n_out = (uint32_t)n;
+    const double pm = __builtin_fma(x, kTwoOverPi, kRoundMagic);
+    n_out = (uint32_t)__double2loint(pm);
+    const double nd = pm - kRoundMagic;
     if constexpr (FMA) return __builtin_fma(-nd, HPI, x);
     else               return x - nd * HPI;
+}
+
+// 120 <= |x| < 2^30 (round 4): the remainder of x * 2/pi from a three-term 2/pi in double precision instead of glibc's
+// 32x96-bit integer product (reduce_large below: 31 instructions; this: 7, the conversion included).
+//   n  = round(x * 2/pi)                 as above (|n| < 2^30: the magic sum is exact to the integer)
+//   r  = x*c1 - n                        c1 = the leading 29 bits of 2/pi: 24 x 29 bits, the product and the difference exact
+//   r += x*c2 ; r += x*c3                c2, c3 = the next 53 + 53 bits (fused: one rounding each, relative to r)
+//   xr = r * pi/2                        the same double constant glibc multiplies its remainder by (pi63 = pi/2 * 2^-62)
+// r differs from glibc's remainder (a 64-bit fixed-point value truncated below 2^-62 of a quadrant, then rounded to double)
+// in the last place in about one argument of a hundred — and never enough to move either result across a float rounding
+// boundary, nor to pick another quadrant: all 387 973 120 arguments of the range, both signs, both libm builds, give the
+// floats of the integer path (tools/sincos_model.c; without c3 two arguments differ).  Odd symmetry (round-to-nearest
+// is symmetric) lets the signed x go through: quadrant -n and remainder -r reproduce glibc's "n + sign" bookkeeping,
+// so quad = sidx = n exactly as in the small range.  Checked like the small range: exhaustively, CPU model and device.
+__device__ __forceinline__ double reduce_large_quick(double x, uint32_t &n_out)
+{
+    constexpr double C1 = 0x1.45F306Dp-1, C2 = 0x1.9391054A7F09Dp-30, C3 = 0x1.7D1F534DDC0DBp-84;
+    constexpr double HPI = 0x1.921FB54442D18p0;
+    const double pm = __builtin_fma(x, kTwoOverPi, kRoundMagic);
+    n_out = (uint32_t)__double2loint(pm);
+    const double nd = pm - kRoundMagic;
+    double r = __builtin_fma(x, C1, -nd);
+    r = __builtin_fma(x, C2, r);
+    r = __builtin_fma(x, C3, r);
+    return r * HPI;
 }
 
 // the two polynomials on the reduced argument, then quadrant signs and the sin/cos exchange.
@@ -177,13 +214,13 @@ __device__ __forceinline__ void sincosf_glibc(float y, float &sn, float &cs)
         sincos_poly<FMA>(xr, n, n, sn, cs);
         return;
     }
-    // 120 <= |y| < 2^33: every lane takes the fixed-point reduction with the windows cut from registers
-    // (the common case for a stream: theta = 2 pi ratio n passes 120 after a few thousand counters)
-    const bool large = (ax - 0x42f00000u) < (0x50000000u - 0x42f00000u);
+    // 120 <= |y| < 2^30: every lane takes the three-term double-precision reduction
+    // (the common case for a stream: theta = 2 pi ratio n passes 120 after a few thousand counters, and stays below 2^26)
+    const bool large = (ax - 0x42f00000u) < (kLargeQuickEnd - 0x42f00000u);
     if (__builtin_amdgcn_ballot_w64(!large) == 0) {
-        uint32_t quad, sidx;
-        const double xr = reduce_large<true>(xi, quad, sidx);
-        sincos_poly<FMA>(xr, quad, sidx, sn, cs);
+        uint32_t n;
+        const double xr = reduce_large_quick((double)y, n);
+        sincos_poly<FMA>(xr, n, n, sn, cs);
         return;
     }
     sincosf_general<FMA>(y, sn, cs);
@@ -341,7 +378,7 @@ __device__ __forceinline__ void corrector(float ratio, uint32_t n, float &c, flo
 typedef float sc_f32x2 __attribute__((ext_vector_type(2)));
 // path: what the caller knows about all the counters of the WAVEFRONT (a wavefront-uniform value; DevSeg's n_plain /
 // n_large / n_huge give it for free): kPathPlain — every |theta| in [2^-12, 120); kPathLarge — every |theta| in
-// [120, 2^33); kPathAny — nothing known, the function looks and votes.
+// [120, 2^30); kPathAny — nothing known, the function looks and votes.
 constexpr int kPathAny = 0, kPathPlain = 1, kPathLarge = 2;
 
 template <bool FMA>
@@ -381,7 +418,7 @@ __device__ __forceinline__ void corrector4_f(float ratio, sc_f32x2 f01, sc_f32x2
         }
         // every |theta| in [2^-12, 120)  (nan / inf have the largest magnitudes: they fail the upper bound)
         all_plain = __builtin_amdgcn_ballot_w64(!(lo >= 0x39800000u && hi < 0x42f00000u)) == 0;
-        all_large = !all_plain && __builtin_amdgcn_ballot_w64(!(lo >= 0x42f00000u && hi < 0x50000000u)) == 0;
+        all_large = !all_plain && __builtin_amdgcn_ballot_w64(!(lo >= 0x42f00000u && hi < kLargeQuickEnd)) == 0;
     }
     if (all_plain) {
 #pragma unroll
@@ -393,13 +430,13 @@ __device__ __forceinline__ void corrector4_f(float ratio, sc_f32x2 f01, sc_f32x2
             cs[k] = sc_f32x2{c, sn};
         }
     } else if (all_large) {
-        // every |theta| in [120, 2^33)
+        // every |theta| in [120, 2^30)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            uint32_t quad, sidx;
+            uint32_t q;
             float sn, c;
-            const double xr = reduce_large<true>(__float_as_uint(th[k]), quad, sidx);
-            sincos_poly<FMA>(xr, quad, sidx, sn, c);
+            const double xr = reduce_large_quick((double)th[k], q);
+            sincos_poly<FMA>(xr, q, q, sn, c);
             cs[k] = sc_f32x2{c, sn};
         }
     } else {

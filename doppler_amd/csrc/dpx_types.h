@@ -29,7 +29,7 @@ struct DevSeg {
     uint32_t flags;
     // |theta(n)| never decreases with the counter n (every rounding in fl32(-2 pi * fl32(ratio * fl32(n))) is monotone), so
     // the range of sincosf's argument paths is three counters, found on the host by bisection with the same f32 products:
-    // the first n whose |theta| bits reach 2^-12 / 120 / 2^33 (0xffffffff: none).  A tile whose counters lie inside
+    // the first n whose |theta| bits reach 2^-12 / 120 / 2^30 (0xffffffff: none).  A tile whose counters lie inside
     // [n_plain, n_large) or [n_large, n_huge) knows its path from two scalar comparisons (dpx_sincos.h, corrector4_f).
     uint32_t n_plain, n_large, n_huge;
     uint32_t pad;

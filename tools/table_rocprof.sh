@@ -6,12 +6,14 @@
 set -u
 REPO=$PWD
 export TMPDIR=/tmp
-OUTMD=$REPO/gpurun_out/${ROUND:-r03}_table_rocprof.md
+OUTMD=$REPO/gpurun_out/${ROUND:-r04}_table_rocprof${SUFFIX:-}.md
 ITERS=${ITERS:-300}
 echo "| row | kernel | launches | median us | avg us | min us | GB/s (median) | % of 8 TB/s (median) | % (avg) | % (best) |" > $OUTMD
 echo "|---|---|---|---|---|---|---|---|---|---|" >> $OUTMD
+# ONLY='regex' keeps the rows whose label matches (a quick subset between full tables)
 row() {   # label bytes_per_sample case [opts...]
   local label=$1; local bps=$2; shift 2
+  if [ -n "${ONLY:-}" ] && ! [[ "$label" =~ $ONLY ]]; then return; fi
   rm -rf /tmp/tr; mkdir -p /tmp/tr; cd /tmp
   rocprofv3 --kernel-trace --stats -d /tmp/tr -o run -- python $REPO/tools/prof_case.py "$@" iters=$ITERS > /tmp/tr/log 2>&1
   cd $REPO
