@@ -23,7 +23,7 @@ $(LIBDIR)/dpx_kernels.o: $(CSRC)/dpx_kernels.hip $(CSRC)/dpx_sincos.h $(CSRC)/dp
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -mllvm -amdgpu-kernarg-preload-count=16 -c $< -o $@
 
-$(LIBDIR)/dpx_api.o: $(CSRC)/dpx_api.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h $(CSRC)/host/orbit.h $(CSRC)/host/schedule.h include/doppler_hip.h
+$(LIBDIR)/dpx_api.o: $(CSRC)/dpx_api.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h $(CSRC)/host/orbit.h $(CSRC)/host/schedule.h include/doppler_hip.h include/doppler_hip_debug.h include/doppler_hip_host.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
@@ -42,7 +42,7 @@ $(LIB): $(OBJS)
 BINDIR := doppler_amd/bin
 cli: $(BINDIR)/doppler
 
-$(BINDIR)/doppler: $(CSRC)/cli/main.cpp $(CSRC)/cli/args.cpp $(CSRC)/cli/args.h $(LIB)
+$(BINDIR)/doppler: $(CSRC)/cli/main.cpp $(CSRC)/cli/args.cpp $(CSRC)/cli/args.h include/doppler_hip.h include/doppler_hip_debug.h include/doppler_hip_host.h $(LIB)
 	@mkdir -p $(BINDIR)
 	g++ -O2 -std=c++17 -ffp-contract=off -Wall -pthread -Iinclude $(CSRC)/cli/main.cpp $(CSRC)/cli/args.cpp \
 	    -o $@ -L$(LIBDIR) -ldoppler_hip -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,$(ROCM)/lib

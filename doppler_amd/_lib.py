@@ -1,4 +1,4 @@
-"""ctypes binding of include/doppler_hip.h (doppler_amd/lib/libdoppler_hip.so).
+"""ctypes binding of include/doppler_hip.h, doppler_hip_host.h and doppler_hip_debug.h (doppler_amd/lib/libdoppler_hip.so).
 
 Loading never falls back to anything: a missing library or a missing symbol
 raises ImportError naming the build command.
@@ -9,7 +9,9 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdoppler_hip.so")
-HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "doppler_hip.h")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+HEADER_PATH = os.path.join(INCLUDE_DIR, "doppler_hip.h")                # the boundary proper
+HEADERS = ("doppler_hip.h", "doppler_hip_host.h", "doppler_hip_debug.h")   # everything the library exports
 
 FMT_I16, FMT_F32 = 0, 1
 BUFFER_SIZE = 8192
@@ -40,16 +42,16 @@ class StreamStats(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("rows_mult", C.c_uint32), ("rows_maxl", C.c_uint32), ("rows_r", C.c_uint32), ("walk_waves", C.c_uint32),
-                ("walk_rows", C.c_uint32), ("walk_compute", C.c_int32), ("walk_table_rows", C.c_uint32), ("rows_compute", C.c_uint32),
-                ("walk_tilemin", C.c_uint64), ("walk_span", C.c_uint32), ("walk_flags", C.c_uint32)]
+    _fields_ = [("rows_mult", C.c_uint32), ("rows_maxl", C.c_uint32), ("rows_r", C.c_uint32), ("rows_compute", C.c_uint32),
+                ("walk_waves", C.c_uint32), ("walk_span", C.c_uint32), ("walk_flags", C.c_uint32), ("reserved", C.c_uint32),
+                ("walk_tilemin", C.c_uint64)]
 
 
 def make_options(opts):
     """None or a dict of dpx_options fields -> pointer argument (None = defaults)."""
     if not opts:
         return None
-    o = Options(walk_compute=-1)
+    o = Options()
     for k, v in opts.items():
         if k not in dict(Options._fields_):
             raise KeyError("unknown option %r" % k)
@@ -57,12 +59,15 @@ def make_options(opts):
     return C.byref(o)
 
 
-def declared_symbols():
-    """Every function include/doppler_hip.h declares (parsed from the header text)."""
-    with open(HEADER_PATH) as f:
-        text = f.read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(dpx_[a-z0-9_]+)\s*\(", text)))
+def declared_symbols(header=None):
+    """Every function the public headers declare (parsed from the header text); header: one of HEADERS, default all."""
+    names = set()
+    for h in ([header] if header else HEADERS):
+        with open(os.path.join(INCLUDE_DIR, h)) as f:
+            text = f.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(dpx_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 _vp, _sz, _u32, _u64, _i, _f = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int, C.c_float
@@ -87,7 +92,7 @@ _SIGNATURES = {
     "dpx_find_reset": (_i, [_f, _u32, _u32, _u64, _P(_u32), _P(_i)]),
     "dpx_samplenum_after": (_i, [_f, _u32, _u32, _u64, _P(_u32)]),
     "dpx_plan_describe": (_i, [_P(Segment), _sz, _u32, _u32, _i, _P(Stretch), _sz, _P(_sz), _P(_u32)]),
-    "dpx_plan_simulate": (_i, [_P(Segment), _sz, _u32, _u32, _i, _i, _i, _vp, _vp, _vp, _u64]),
+    "dpx_plan_simulate": (_i, [_P(Segment), _sz, _u32, _u32, _i, _i, _i, _vp, _i, _i, _vp, _vp, _u64]),
     "dpx_plan_layout": (_i, [_P(Segment), _sz, _u32, _u32, _i, _i, _i, _vp, _P(Layout)]),
     "dpx_set_options": (_i, [_vp, _vp]),
     "dpx_track_schedule": (_i, [_vp, _sz, _u32, _u32, C.c_int32, _i, _i, _u64, _vp, _sz, _P(_sz)]),

@@ -46,6 +46,8 @@
 #include <vector>
 
 #include "../../../include/doppler_hip.h"
+#include "../../../include/doppler_hip_debug.h"   // dpx_stream_get_stats (the --stats line), dpx_set_tuning (DOPPLER_VARIANT)
+#include "../../../include/doppler_hip_host.h"    // track schedule, orbit
 #include "../host/orbit.h"
 #include "../host/schedule.h"
 #include "args.h"

@@ -16,6 +16,8 @@
 #include <vector>
 
 #include "../../include/doppler_hip.h"
+#include "../../include/doppler_hip_debug.h"
+#include "../../include/doppler_hip_host.h"
 #include "dpx_planner.h"
 #include "dpx_types.h"
 #include "host/orbit.h"
@@ -87,9 +89,8 @@ struct DevPlan {
     dpx::WalkSeg *walk = nullptr;   // one descriptor per 2^kWalkHintShift workgroups of the walk launch
     dpx::LeftRange *left = nullptr;
     uint32_t *left_hint = nullptr;
-    void *sink = nullptr;          // where walk-kernel lanes without a sample store
     void *lut = nullptr;
-    std::vector<char> image;       // host copy of everything before `sink`, source of the one upload
+    std::vector<char> image;       // host copy of everything before the tables, source of the one upload
 };
 
 struct dpx_plan {
@@ -123,8 +124,7 @@ int ensure_stage(dpx_ctx *ctx, size_t in_bytes, size_t out_bytes)
     return DPX_OK;
 }
 
-// the legacy cast exists in the tile kernel only
-int plan_choice(const dpx_ctx *ctx) { return ctx->i16_cast == DPX_CAST_LEGACY_X86 ? (int)dpx::kChooseTileOnly : ctx->choice; }
+int plan_choice(const dpx_ctx *ctx) { return ctx->choice; }
 
 dpx::LaunchGeom geometry(const dpx_ctx *ctx)
 {
@@ -133,7 +133,6 @@ dpx::LaunchGeom geometry(const dpx_ctx *ctx)
     g.vecs = ctx->vecs;
     g.autosel = ctx->geom_auto ? 1 : 0;
     g.legacy_cast = ctx->i16_cast == DPX_CAST_LEGACY_X86 ? 1 : 0;
-    if (g.legacy_cast) { g.block = 256; g.vecs = 1; g.autosel = 0; }
     return g;
 }
 
@@ -153,9 +152,6 @@ dpx::PlanTuning tuning_of(const dpx_options *o)
     t.rows_r = o->rows_r;
     t.rows_compute = o->rows_compute;
     t.walk_waves = o->walk_waves;
-    t.walk_rows = o->walk_rows;
-    t.walk_compute = o->walk_compute;
-    t.walk_table_rows = o->walk_table_rows;
     t.walk_tilemin = o->walk_tilemin;
     t.walk_span = o->walk_span;
     t.walk_flags = o->walk_flags;
@@ -192,8 +188,7 @@ int materialize(dpx_ctx *ctx, const dpx::PlanResult &plan, DevPlan &dev, bool fm
     const size_t left_bytes = align256(plan.left.size() * sizeof(dpx::LeftRange));
     const size_t lhint_bytes = align256(plan.left_hint.size() * sizeof(uint32_t));
     const size_t lut_bytes = align256(plan.lut_entries * 8 + 64);
-    const size_t sink_bytes = align256(dpx::kWalkSinkBytes);
-    const size_t need = seg_bytes + hint_bytes + walk_bytes + left_bytes + lhint_bytes + sink_bytes + lut_bytes;
+    const size_t need = seg_bytes + hint_bytes + walk_bytes + left_bytes + lhint_bytes + lut_bytes;
     if (need > dev.cap) {
         if (dev.buf) {
             DPX_HIP(hipStreamSynchronize(st));
@@ -212,7 +207,6 @@ int materialize(dpx_ctx *ctx, const dpx::PlanResult &plan, DevPlan &dev, bool fm
     dev.walk = reinterpret_cast<dpx::WalkSeg *>(p);          p += walk_bytes;
     dev.left = reinterpret_cast<dpx::LeftRange *>(p);        p += left_bytes;
     dev.left_hint = reinterpret_cast<uint32_t *>(p);         p += lhint_bytes;
-    dev.sink = p;                                            p += sink_bytes;
     dev.lut = p;
     // one host image of all the small tables, one copy (every hipMemcpyAsync from pageable memory costs 5-8 us)
     const size_t image_bytes = seg_bytes + hint_bytes + walk_bytes + left_bytes + lhint_bytes;
@@ -252,10 +246,9 @@ int run_plan(const dpx::PlanResult &plan, const DevPlan &dev, const void *d_in, 
     for (const dpx::Launch &ln : plan.launches) {
         int rc;
         if (ln.kind == 0)
-            rc = dpx::launch_rows(d_in, in_fmt, d_out, out_fmt, dev.segs, dev.lut, ln.rows, fma, st);
+            rc = dpx::launch_rows(d_in, in_fmt, d_out, out_fmt, dev.segs, dev.lut, ln.rows, fma, g.legacy_cast, st);
         else if (ln.kind == 2)
-            rc = dpx::launch_walk(d_in, in_fmt, d_out, out_fmt, dev.segs, dev.lut, dev.walk, dev.left,
-                                  dev.left_hint, dev.sink, ln.walk, fma, st);
+            rc = dpx::launch_span(d_in, in_fmt, d_out, out_fmt, dev.segs, dev.walk, dev.left, dev.left_hint, ln.walk, fma, g.legacy_cast, st);
         else
             rc = dpx::launch_tiles(d_in, in_fmt, d_out, out_fmt, dev.segs, (uint32_t)plan.segs.size(), dev.hint,
                                    dev.lut, ln.tiles, fma, g, st);
@@ -478,9 +471,12 @@ int dpx_set_tuning(dpx_ctx *ctx, int block, int vecs, int variant)
     }
     if (block != 0 && block != 128 && block != 256) return fail(DPX_ERR_ARG, "block must be 128 or 256");
     if (vecs != 0 && vecs != 1 && vecs != 2) return fail(DPX_ERR_ARG, "vecs must be 1 or 2");
-    if (block) ctx->block = block;
-    if (vecs) ctx->vecs = vecs;
-    if (block || vecs) ctx->geom_auto = false;
+    {   // the two 1024-sample tiles that are built: 256 lanes x 1 vector, 128 x 2 (naming one half picks the other half to match)
+        int b = block ? block : (vecs ? (vecs == 1 ? 256 : 128) : ctx->block);
+        int v = vecs ? vecs : (block ? (block == 256 ? 1 : 2) : ctx->vecs);
+        if (b * v != 256) return fail(DPX_ERR_ARG, "tile geometry must be 256 x 1 or 128 x 2");
+        if (block || vecs) { ctx->block = b; ctx->vecs = v; ctx->geom_auto = false; }
+    }
     ctx->choice = choice_of(variant);
     ctx->variant = variant >= 3 ? 0 : variant;
     return DPX_OK;
@@ -492,9 +488,8 @@ int dpx_set_options(dpx_ctx *ctx, const dpx_options *opt)
     if (opt) {
         if (opt->rows_r != 0 && opt->rows_r != 2 && opt->rows_r != 4 && opt->rows_r != 8) return fail(DPX_ERR_ARG, "rows_r must be 2, 4 or 8");
         const uint32_t ww = opt->walk_waves;
-        if (ww != 0 && (ww < 2 || ww > 8 || ww == 7)) return fail(DPX_ERR_ARG, "walk_waves must be 2, 3, 4, 5, 6 or 8");
-        if (opt->walk_rows > 4) return fail(DPX_ERR_ARG, "walk_rows must be 1..4");
-        if (opt->walk_span > 4096) return fail(DPX_ERR_ARG, "walk_span must be 0 (default), 1 (walk kernel) or 2..4096 rows");
+        if (ww != 0 && ww != 2 && ww != 4 && ww != 5 && ww != 8) return fail(DPX_ERR_ARG, "walk_waves must be 2, 4, 5 or 8");
+        if (opt->walk_span == 1 || opt->walk_span > 4096) return fail(DPX_ERR_ARG, "walk_span must be 0 (the planner's cut) or 2..4096 rows");
     }
     ctx->tuning = tuning_of(opt);
     return DPX_OK;
@@ -760,9 +755,9 @@ int dpx_plan_describe(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
 
 int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
                       uint32_t samplenum0, int block, int vecs, int variant, const dpx_options *opt,
-                      uint32_t *counters, uint8_t *writes, uint64_t n_samples)
+                      int in_fmt, int out_fmt, uint32_t *counters, uint8_t *writes, uint64_t n_samples)
 {
-    if ((n_segs && !segs) || !counters || !writes) return fail(DPX_ERR_ARG, "bad argument");
+    if ((n_segs && !segs) || !counters || !writes || !fmt_ok(in_fmt) || !fmt_ok(out_fmt)) return fail(DPX_ERR_ARG, "bad argument");
     dpx::PlanResult plan;
     uint32_t sn = samplenum0;
     const int v = variant >= 3 ? 0 : variant;
@@ -775,7 +770,7 @@ int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerat
     g.vecs = vecs ? vecs : 2;
     dpx::finalize(plan, g.tile(), choice_of(variant), tuning_of(opt));
     memset(writes, 0, n_samples);
-    dpx::simulate(plan, counters, writes);
+    dpx::simulate(plan, counters, writes, in_fmt, out_fmt);
     return DPX_OK;
 }
 
@@ -814,8 +809,8 @@ int dpx_plan_layout(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
         out->leftover_ranges = (uint32_t)plan.left.size() - 1;
         for (size_t i = 0; i + 1 < plan.walk.size(); ++i) {
             if (plan.walk[i].upw == 0) continue;                  // a group of leftover blocks
-            out->walk_workgroups += (plan.walk[i].nw + 7u) & ~7u; // chunks are padded to multiples of 8 workgroups
-            if (plan.walk[i].row0 != 0) continue;                 // one descriptor per row chunk: count matrices once
+            out->walk_workgroups += (plan.walk[i].nwg + 7u) & ~7u; // spans are padded to multiples of 8 workgroups
+            if (plan.walk[i].row0 != 0) continue;                 // one descriptor per span: count matrices once
             ++out->walk_matrices;
             out->walk_samples += plan.walk[i].E - plan.walk[i].A;
         }

@@ -28,10 +28,6 @@
 #error "dpx_kernels.hip is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
 #endif
 
-#ifndef DPX_WALK_ACTIVE_ONLY
-#define DPX_WALK_ACTIVE_ONLY 1
-#endif
-
 namespace dpx {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -95,9 +91,12 @@ __device__ __forceinline__ int f32_as_i32_sat(float x)
 }
 
 // main.rs:77-83: i = (re * 32767.0) as i16, little-endian I then Q.
-// LEGACY (dpx_set_i16_cast(DPX_CAST_LEGACY_X86); tile kernel and the pack operator only): the cast as a 2016 rustc compiled
-// it for x86-64 — CVTTSS2SI into a 32-bit register, low half kept: truncate, then wrap modulo 2^16; NaN and |x| >= 2^31
-// give 0x80000000, low half 0.  v_cvt_i32_f32 differs from CVTTSS2SI only at x >= 2^31 (0x7fffffff: low half 0xffff).
+// LEGACY (dpx_set_i16_cast(DPX_CAST_LEGACY_X86); every kernel, round 4): the cast as a 2016 rustc compiled it for
+// x86-64 — CVTTSS2SI into a 32-bit register, low half kept: truncate, then wrap modulo 2^16; NaN and |x| >= 2^31 give
+// 0x80000000, low half 0.  v_cvt_i32_f32 differs from CVTTSS2SI only at x >= 2^31 (0x7fffffff: low half 0xffff).
+// The mode reaches a kernel as a launch-uniform flag; the kernels branch on it ONCE per row / per four samples, around
+// two instantiations of their pack code (a test inside every pack would cut the mix of four samples into pieces the
+// scheduler cannot interleave: measured 2-3 points on the span kernel's short matrices).
 template <bool RAW = false, bool LEGACY = false>
 __device__ __forceinline__ uint32_t pack_i16(float re, float im)
 {
@@ -160,6 +159,35 @@ __device__ __forceinline__ void quad_set(Quad<FMT> &q, int k, float re, float im
     }
 }
 
+// four samples at once, the cast mode decided by ONE uniform branch (see pack_i16)
+template <int FMT, bool RAW>
+__device__ __forceinline__ void quad_set4(Quad<FMT> &q, const float (&re)[4], const float (&im)[4], bool legacy)
+{
+    if constexpr (FMT == DPX_FMT_I16) {
+        if (legacy) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) quad_set<FMT, RAW, true>(q, k, re[k], im[k]);
+            return;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) quad_set<FMT, RAW, false>(q, k, re[k], im[k]);
+}
+
+// S packed i16 samples of a row vector, the cast mode decided by ONE uniform branch (see pack_i16)
+template <bool RAW, bool LEGACY, int S>
+__device__ __forceinline__ void pack_row(const float (&re)[S], const float (&im)[S], uint32_t (&o)[S])
+{
+#pragma unroll
+    for (int k = 0; k < S; ++k) o[k] = pack_i16<RAW, LEGACY>(re[k], im[k]);
+}
+template <bool RAW, int S>
+__device__ __forceinline__ void pack_row(const float (&re)[S], const float (&im)[S], uint32_t (&o)[S], bool legacy)
+{
+    if (legacy) pack_row<RAW, true, S>(re, im, o);
+    else        pack_row<RAW, false, S>(re, im, o);
+}
+
 // one sample at a time: ragged tiles and stretch boundaries only
 template <int FMT, bool RAW = false>
 __device__ __forceinline__ void load_one(const uint8_t *base, uint64_t g, float &re, float &im)
@@ -173,11 +201,11 @@ __device__ __forceinline__ void load_one(const uint8_t *base, uint64_t g, float 
     }
 }
 
-template <int FMT, bool RAW = false, bool LEGACY = false>
-__device__ __forceinline__ void store_one(uint8_t *base, uint64_t g, float re, float im)
+template <int FMT, bool RAW = false>
+__device__ __forceinline__ void store_one(uint8_t *base, uint64_t g, float re, float im, bool legacy = false)
 {
     if constexpr (FMT == DPX_FMT_I16) {
-        *reinterpret_cast<uint32_t *>(base + g * 4) = pack_i16<RAW, LEGACY>(re, im);
+        *reinterpret_cast<uint32_t *>(base + g * 4) = legacy ? pack_i16<RAW, true>(re, im) : pack_i16<RAW, false>(re, im);
     } else {
         u32x2 w;
         w[0] = __float_as_uint(re);
@@ -207,15 +235,15 @@ __device__ __forceinline__ uint32_t counter_at(const DevSeg &sg, uint64_t j)
 //   * rows kernel (const mode): the stream is viewed as a matrix whose row
 //     length is a multiple of the period, so the two rows a wavefront handles
 //     share one 32-byte table read per lane and need no phase arithmetic;
-//   * walk kernel (track mode, hundreds of stretches in one launch): same idea
+//   * span kernel (track mode, hundreds of stretches in one launch): same idea
 //     with rows shifted onto 128-byte lines and the 288 correctors of a column
-//     window shared by ten rows through LDS (the only LDS use in this file);
+//     window evaluated by the workgroup and shared by its rows through LDS;
 //   * tile kernel: whatever the two above leave.
 
 // ---- per-sample evaluation (ragged ranges and stretch boundaries)
-template <int IN_FMT, int OUT_FMT, bool FMA, bool LEGACY = false>
+template <int IN_FMT, int OUT_FMT, bool FMA>
 __device__ __forceinline__ void one_sample(const uint8_t *in, uint8_t *out, const DevSeg *segs,
-                                           uint32_t n_segs, uint32_t si, uint64_t g)
+                                           uint32_t n_segs, uint32_t si, uint64_t g, bool legacy)
 {
     while (si + 1 < n_segs && segs[si].first + segs[si].count <= g) ++si;
     const DevSeg sx = segs[si];
@@ -223,7 +251,7 @@ __device__ __forceinline__ void one_sample(const uint8_t *in, uint8_t *out, cons
     corrector<FMA>(sx.ratio, counter_at(sx, g - sx.first), c, s);
     load_one<IN_FMT, kRawI16<IN_FMT, OUT_FMT>>(in, g, a, b);
     mix(a, b, c, s, re, im);
-    store_one<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>, LEGACY>(out, g, re, im);
+    store_one<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(out, g, re, im, legacy);
 }
 
 // ---- rows kernel: one wavefront, R rows of one tabulated periodic stretch
@@ -253,13 +281,14 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
     constexpr int S = RowVec<IN_FMT, OUT_FMT>::S;
     constexpr int IB = Fmt<IN_FMT>::kBytes, OB = Fmt<OUT_FMT>::kBytes;
     const uint32_t lane = threadIdx.x;
+    const bool legacy = (div_s >> 31) != 0;                    // dpx_set_i16_cast, in the spare bits of a preloaded argument
 
     // the workgroups of the ragged ranges come first in the grid: their sincos work then overlaps the memory-bound
     // matrix instead of forming a tail
     if (blockIdx.x >= n_extra) {
         const uint32_t b = blockIdx.x - n_extra;
         // (row group, column slice) = divmod(b, cols), exact magic-number division
-        const uint32_t rg = (uint32_t)(((uint64_t)b * div_m) >> div_s);
+        const uint32_t rg = (uint32_t)(((uint64_t)b * div_m) >> (div_s & 63u));
         const uint32_t col = b - rg * cols;
         const uint32_t cs0 = (col * kRowsLanes + lane) * S;   // first sample of this lane in the row
         if (cs0 >= L) return;                                  // ragged last column slice
@@ -324,15 +353,13 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
             }
             uint8_t *op = out + (g0 + (uint64_t)r * L) * OB;
             if constexpr (OUT_FMT == DPX_FMT_I16) {
+                uint32_t pk[S];
+                pack_row<kRawI16<IN_FMT, OUT_FMT>, S>(re, im, pk, legacy);
                 if constexpr (S == 4) {
-                    u32x4 o;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[k], im[k]);
+                    const u32x4 o = {pk[0], pk[1], pk[2], pk[3]};
                     __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(op));
                 } else {
-                    u32x2 o;
-                    o[0] = pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[0], im[0]);
-                    o[1] = pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[1], im[1]);
+                    const u32x2 o = {pk[0], pk[1]};
                     __builtin_nontemporal_store(o, reinterpret_cast<u32x2 *>(op));
                 }
             } else {
@@ -355,13 +382,13 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
             const uint64_t idx = e0 + (uint64_t)k * kRowsLanes + lane;
             if (idx >= total) break;
             const uint64_t g = idx < head ? ra.r0 + idx : ra.B + (idx - head);
-            one_sample<IN_FMT, OUT_FMT, FMA>(in, out, segs, ra.n_segs, ra.seg_lo, g);
+            one_sample<IN_FMT, OUT_FMT, FMA>(in, out, segs, ra.n_segs, ra.seg_lo, g, legacy);
         }
     }
 }
 
 // ---- tile kernel: any mixture of stretches; workgroup b handles tile tile_lo + b and exits
-template <int IN_FMT, int OUT_FMT, bool FMA, int BLOCK, int V, bool LEGACY = false>
+template <int IN_FMT, int OUT_FMT, bool FMA, int BLOCK, int V>
 __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__ in,
                                                      uint8_t *__restrict__ out,
                                                      const DevSeg *__restrict__ segs,
@@ -373,6 +400,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
     constexpr uint32_t SPL = kSamplesPerLane;
     constexpr uint32_t TILE = BLOCK * SPL * V;
     const uint32_t tid = threadIdx.x;
+    const bool legacy = ta.legacy != 0;                   // dpx_set_i16_cast: uniform
     const uint64_t tile = ta.tile_lo + blockIdx.x;
     const uint64_t t0 = tile * TILE;
     const bool in_mask = t0 >= ta.m0 && t0 + TILE <= ta.m1;
@@ -408,13 +436,14 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
 #pragma unroll
             for (int k = 0; k < (int)SPL; ++k) cs[k] = tab[e + k];
             Quad<OUT_FMT> qo;
+            float re[SPL], im[SPL];
 #pragma unroll
             for (int k = 0; k < (int)SPL; ++k) {
-                float a, b, re, im;
+                float a, b;
                 quad_get<IN_FMT, kRawI16<IN_FMT, OUT_FMT>>(qin[v], k, a, b);
-                mix(a, b, cs[k].x, cs[k].y, re, im);
-                quad_set<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>, LEGACY>(qo, k, re, im);
+                mix(a, b, cs[k].x, cs[k].y, re[k], im[k]);
             }
+            quad_set4<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(qo, re, im, legacy);
             store_quad<OUT_FMT>(out, t0 + (uint64_t)(v * BLOCK + tid) * SPL, qo);
         }
     } else if (whole && (sg.period == 0 || sg.period >= 4)) {
@@ -462,13 +491,14 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
                 corrector4<FMA>(sg.ratio, n, cs);
             }
             Quad<OUT_FMT> qo;
+            float re[SPL], im[SPL];
 #pragma unroll
             for (int k = 0; k < (int)SPL; ++k) {
-                float a, b, re, im;
+                float a, b;
                 quad_get<IN_FMT, kRawI16<IN_FMT, OUT_FMT>>(qin[v], k, a, b);
-                mix(a, b, cs[k].x, cs[k].y, re, im);
-                quad_set<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>, LEGACY>(qo, k, re, im);
+                mix(a, b, cs[k].x, cs[k].y, re[k], im[k]);
             }
+            quad_set4<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(qo, re, im, legacy);
             store_quad<OUT_FMT>(out, t0 + (uint64_t)(v * BLOCK + tid) * SPL, qo);
         }
     } else {
@@ -477,25 +507,17 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
             const uint64_t g = t0 + o;
             if (g < ta.m0) continue;
             if (g >= ta.m1) break;
-            one_sample<IN_FMT, OUT_FMT, FMA, LEGACY>(in, out, segs, n_segs, si, g);
+            one_sample<IN_FMT, OUT_FMT, FMA>(in, out, segs, n_segs, si, g, legacy);
         }
     }
 }
 
 
-// ---- walk kernel: many tabulated stretches in one launch (dpx_types.h, WalkSeg).
-// A workgroup = WAVES wavefronts x U rows (U = 1..4, chosen per row chunk by the planner) of ONE 256-sample column
-// window: the window's correctors (288 entries, whatever the rows' shifts) are read from a plan-time table once — or
-// evaluated by the workgroup itself — staged in LDS, and used by all the rows.  One shot, no loop, no divergent
-// branch: the compiler serialises loads that sit in divergent blocks, so a lane without a sample (past the end of its
-// row, or a row past the end of the chunk) loads from the start of the matrix instead and stores to a scratch area
-// (`sink`).  The cost of a workgroup is largely fixed (descriptor fetch, slice, barrier: about 1.2 rows' worth,
-// profiles/r02_walk.md), so the planner makes chunks as tall as a workgroup can take (up to 4 rows per wavefront)
-// instead of leaving short remainder chunks; the rows-per-wavefront switch below is uniform for the workgroup.
-// Walk kernel, f32 -> i16: loads are 16 bytes per lane (2 samples), which would make the stores 8 bytes per lane — and
-// 8-byte stores run at 2.4 TB/s in this kernel (measured; 16-byte stores with two 16-byte loads per lane at a 32-byte
-// lane stride: 5.0 TB/s).  So the packed results of a row go through a wavefront-private kilobyte of LDS and leave as
-// one 16-byte store per lane: both sides fully coalesced.
+// ---- column windows of the span kernel (below).
+// f32 -> i16: loads are 16 bytes per lane (2 samples), which would make the stores 8 bytes per lane — and 8-byte stores
+// run at 2.4 TB/s in this kernel (measured; 16-byte stores with two 16-byte loads per lane at a 32-byte lane stride:
+// 5.0 TB/s).  So the packed results of a row go through a wavefront-private kilobyte of LDS and leave as one 16-byte
+// store per lane: both sides fully coalesced.
 template <int IN_FMT, int OUT_FMT> struct WalkVec {
     static constexpr int S = RowVec<IN_FMT, OUT_FMT>::S;
     static constexpr bool kTranspose = IN_FMT == DPX_FMT_F32 && OUT_FMT == DPX_FMT_I16;
@@ -504,14 +526,9 @@ template <int IN_FMT, int OUT_FMT> struct WalkVec {
     // vector per lane per row).  Such a window is therefore shared by TWO workgroups, 128 columns each (the grid is
     // doubled at launch; the plan, which does not know the formats, is unchanged).
     static constexpr int kSplit = (S == 2 && !kTranspose) ? 2 : 1;
-    // The opposite — TWO adjacent windows (512 columns, two vectors per lane per row, one slice of 544 correctors) per
-    // i16 -> i16 workgroup, half as many workgroups — is built in (-DDPX_WALK_MERGE=2) and measures 3-5 points slower on
-    // replays and const-mode walks alike (profiles/r02_walk.md): it is not the number of workgroups that costs.
-#ifndef DPX_WALK_MERGE
-#define DPX_WALK_MERGE 1
-#endif
-    static constexpr int kMerge = (S == 4) ? DPX_WALK_MERGE : 1;
-    static constexpr uint32_t kCols = kWalkWindow * kMerge / kSplit;     // columns a workgroup takes
+    // (The opposite — two adjacent windows per i16 -> i16 workgroup, two vectors per lane per row — measured 3-5 points
+    // slower on replays and const-mode walks alike: profiles/r02_walk.md.)
+    static constexpr uint32_t kCols = kWalkWindow / kSplit;              // columns a workgroup takes
     static constexpr uint32_t kEntries = kCols + kWalkPad;               // slice entries it needs
 };
 
@@ -529,237 +546,10 @@ template <int S, uint32_t ENTRIES> struct SlicePlanes {
     static __device__ __forceinline__ uint32_t index(uint32_t e) { return (e & (kPlanes - 1)) * kStride + (e >> kLog2); }
 };
 
-// everything a wavefront does for its U rows of window w (after the descriptor and, in table mode, the slice loads)
-template <int IN_FMT, int OUT_FMT, bool FMA, int WAVES, int U, int TL>
-__device__ __forceinline__ void walk_rows(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint8_t *__restrict__ sink,
-                                          const WalkSeg &ws, uint32_t w, uint32_t half, uint32_t wave, uint32_t lane, uint32_t tid, bool compute,
-                                          const float2 (&t0)[TL], const float2 (&t1)[TL], float2 *slice, uint32_t *xpose)
-{
-    constexpr int S = WalkVec<IN_FMT, OUT_FMT>::S;                // samples per lane per vector: 4 or 2
-    typedef WalkVec<IN_FMT, OUT_FMT> WV;
-    constexpr int NV = (int)WV::kCols / (kRowsLanes * S);         // vectors per lane per row: 1 (2 for f32 -> i16)
-    constexpr uint32_t kEntries = WV::kEntries;                   // 288, or 160 for half a window
-    const uint32_t col0 = w * kWalkWindow + half * WV::kCols;     // first column of this workgroup (w: its first window)
-    constexpr int THREADS = WAVES * 64;
-    constexpr int IB = Fmt<IN_FMT>::kBytes, OB = Fmt<OUT_FMT>::kBytes;
-    constexpr int QW = S * IB / 4;                                // input dwords per vector
-    typedef uint32_t qvec __attribute__((ext_vector_type(QW)));
-    constexpr bool XP = WalkVec<IN_FMT, OUT_FMT>::kTranspose;
-    typedef SlicePlanes<S, kEntries> SP;
-
-    const uint32_t r0 = ws.row0 + wave * U;
-    // A wavefront past the last row of the chunk has nothing to load; it still reaches the workgroup's barrier (rounds 1
-    // and 2 let it end before the barrier, relying on s_barrier counting live wavefronts only — hardware behaviour the
-    // language does not promise; the span kernel, which serves every default plan now, never did).
-    const bool idle = r0 >= ws.row_end;                            // uniform
-#if DPX_WALK_ACTIVE_ONLY
-    // Evaluated slices: the wavefronts WITH rows share the evaluation.  The shared loop is unrolled with a compile-time
-    // trip count — a loop with a run-time stride makes the compiler wait for the sample loads at its entry.
-    const uint32_t n_act = (ws.row_end - ws.row0 + U - 1) / U;      // wavefronts with rows: 1..WAVES (uniform)
-#endif
-    qvec qin[U][NV];
-    uint32_t off[U];                                          // slice entry of the row's column 0 (uniform per wavefront)
-    uint8_t *op[U][NV];
-    uint8_t *opx[U];                                          // f32 -> i16: where this lane's 4 consecutive samples go
-    if (!idle) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const bool valid = r0 + u < ws.row_end;
-        const uint64_t ideal = ws.A + (uint64_t)(valid ? r0 + u : 0u) * ws.L;
-        const uint64_t row0 = ideal & ~31ull;                             // whole 128-byte lines on both sides
-        const uint32_t delta = (uint32_t)ideal & 31u;
-        const uint64_t nxt = (ideal + ws.L) & ~31ull;
-        const uint32_t rowlen = valid ? (uint32_t)((nxt < ws.E ? nxt : ws.E) - row0) : 0u;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const uint32_t cl = lane * S + (uint32_t)v * (kRowsLanes * S);   // column inside the window
-            const uint32_t c = col0 + cl;
-            const bool active = c < rowlen;
-            const uint64_t g = active ? row0 + c : ws.A + cl;
-            qin[u][v] = __builtin_nontemporal_load(reinterpret_cast<const qvec *>(in + g * IB));
-            op[u][v] = active ? out + g * OB : sink + tid * 16;
-        }
-        off[u] = kWalkPad - delta;
-        const uint32_t c4 = col0 + lane * 4;
-        opx[u] = c4 < rowlen ? out + (row0 + c4) * OB : sink + tid * 16;
-    }
-    }
-
-    if (compute && !(DPX_WALK_ACTIVE_ONLY && idle)) {         // uniform for the wavefront
-        // thread j evaluates entry j (threads 0..31 also entry 256 + j) with the bit-exact sincos — after the sample
-        // loads above have been issued, so the evaluation runs in the shadow of the HBM latency
-        const uint32_t P = ws.period;
-        // counter of column c: ((phase + c) mod P) + 1, c = 256 w + j - kWalkPad >= -kWalkPad
-        const uint32_t ub = ws.phase + col0;                  // < period + L + 255 < 2^24
-#if DPX_WALK_ACTIVE_ONLY
-        const uint32_t stride = n_act * kRowsLanes;
-        constexpr int kMaxIt = ((int)kEntries + kRowsLanes - 1) / kRowsLanes;      // one wavefront alone: 5 (3 for half a window)
-#pragma unroll
-        for (int it = 0; it < kMaxIt; ++it) {
-            if ((uint32_t)it * stride >= kEntries) break;     // uniform
-            const uint32_t j = tid + (uint32_t)it * stride;
-            if (j < kEntries) {
-#else
-        for (uint32_t j = tid; j < kEntries; j += THREADS) {
-            {
-#endif
-                uint32_t t;
-                if (ws.L == P) {                              // P >= kWalkMinL > kWalkPad: at most two wraps
-                    t = ub + j + P - kWalkPad;
-                    t = t >= 2u * P ? t - 2u * P : t;
-                    t = t >= P ? t - P : t;
-                    t = t >= P ? t - P : t;
-                } else {
-                    t = (uint32_t)(((uint64_t)ub + j + (uint64_t)P * kWalkPad - kWalkPad) % P);
-                }
-                float c, sn;
-                corrector<FMA>(ws.ratio, t + 1u, c, sn);
-                slice[SP::index(j)] = make_float2(c, sn);
-            }
-        }
-    } else if (!compute) {
-#pragma unroll
-        for (int i = 0; i < TL; ++i) {
-            const uint32_t j = tid + (uint32_t)i * THREADS;
-            if (j < kEntries / 2) {                             // entries 2j and 2j + 1
-                slice[SP::index(2 * j)] = t0[i];
-                slice[SP::index(2 * j + 1)] = t1[i];
-            }
-        }
-    }
-    __syncthreads();
-    if (idle) return;                                         // a wavefront past the last row (uniform), after the barrier
-
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            float re[S], im[S];
-#pragma unroll
-            for (int k = 0; k < S; ++k) {
-                const uint32_t ok = off[u] + (uint32_t)k;     // uniform: plane and base position of corrector k
-                const float2 cs = slice[(ok & (SP::kPlanes - 1)) * SP::kStride + (ok >> SP::kLog2) + (uint32_t)v * kRowsLanes + lane];
-                float a, bq;
-                if constexpr (IN_FMT == DPX_FMT_I16) unpack_i16<kRawI16<IN_FMT, OUT_FMT>>(qin[u][v][k], a, bq);
-                else { a = __uint_as_float(qin[u][v][2 * k]); bq = __uint_as_float(qin[u][v][2 * k + 1]); }
-                mix(a, bq, cs.x, cs.y, re[k], im[k]);
-            }
-            if constexpr (OUT_FMT == DPX_FMT_I16) {
-                if constexpr (S == 4) {
-                    u32x4 o = {pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[0], im[0]), pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[1], im[1]), pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[2], im[2]),
-                               pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[3], im[3])};
-                    asm volatile("" : "+v"(o));   // keeps the vectoriser from rebuilding the store without its nt flag
-                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(op[u][v]));
-                } else if constexpr (XP) {
-                    u32x2 o;
-                    o[0] = pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[0], im[0]);
-                    o[1] = pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[1], im[1]);
-                    uint32_t *xp = xpose + (wave * U + u) * kWalkWindow + (uint32_t)v * (kRowsLanes * S) + lane * S;
-                    *reinterpret_cast<u32x2 *>(xp) = o;
-                } else {
-                    u32x2 o;
-                    o[0] = pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[0], im[0]);
-                    o[1] = pack_i16<kRawI16<IN_FMT, OUT_FMT>>(re[1], im[1]);
-                    __builtin_nontemporal_store(o, reinterpret_cast<u32x2 *>(op[u][v]));
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < S / 2; ++i) {
-                    u32x4 o;
-                    o[0] = __float_as_uint(re[2 * i]);     o[1] = __float_as_uint(im[2 * i]);
-                    o[2] = __float_as_uint(re[2 * i + 1]); o[3] = __float_as_uint(im[2 * i + 1]);
-                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(op[u][v]) + i);
-                }
-            }
-        }
-        if constexpr (XP) {
-            // the row's 256 packed samples are in LDS (same wavefront: LDS operations execute in order)
-            __builtin_amdgcn_wave_barrier();
-            u32x4 o = *reinterpret_cast<const u32x4 *>(xpose + (wave * U + u) * kWalkWindow + lane * 4);
-            asm volatile("" : "+v"(o));
-            __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(opx[u]));
-        }
-    }
-}
-
-template <int IN_FMT, int OUT_FMT, bool FMA, int THREADS>
-__device__ __forceinline__ void leftover_block(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const LeftRange *__restrict__ left,
-                                               const uint32_t *__restrict__ lhint, const DevSeg *__restrict__ segs, uint32_t e, uint32_t tid);
-
-template <int IN_FMT, int OUT_FMT, bool FMA, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void walk_kernel(const uint8_t *__restrict__ in,
-                                                            uint8_t *__restrict__ out,
-                                                            const float2 *__restrict__ lut_pool,
-                                                            const WalkSeg *__restrict__ wdesc,
-                                                            uint32_t n_left_wg,
-                                                            uint8_t *__restrict__ sink,
-                                                            // ---- leftover path only
-                                                            const LeftRange *__restrict__ left,
-                                                            const uint32_t *__restrict__ lhint,
-                                                            const DevSeg *__restrict__ segs)
-{
-    constexpr int S = WalkVec<IN_FMT, OUT_FMT>::S;
-    constexpr int THREADS = WAVES * 64;
-    constexpr bool XP = WalkVec<IN_FMT, OUT_FMT>::kTranspose;
-    typedef SlicePlanes<S, WalkVec<IN_FMT, OUT_FMT>::kEntries> SPK;
-    __shared__ float2 slice[SPK::kPlanes * SPK::kStride];
-    __shared__ __attribute__((aligned(16))) uint32_t xpose[XP ? WAVES * (int)kWalkMaxRowsPerWave * (int)kWalkWindow : 4];   // packed i16 samples of one row per (wavefront, u); read back as 16-byte vectors
-    const uint32_t tid = threadIdx.x;
-
-    // ONE scalar load before the first sample load: the descriptor of this group of 8 workgroups — a row chunk of a
-    // matrix (replicated per group; chunks start on multiples of 8 workgroups) or a group of leftover blocks.  The
-    // leftover groups (sincos per sample, VALU-bound) are spread evenly between the chunks by the planner, so that they
-    // run beside memory-bound workgroups.
-    constexpr uint32_t kSplit = WalkVec<IN_FMT, OUT_FMT>::kSplit;     // workgroups per window / windows per workgroup
-    constexpr uint32_t kMerge = WalkVec<IN_FMT, OUT_FMT>::kMerge;     // (grid scaled at launch; one of the two is 1)
-    const uint32_t b = blockIdx.x * kMerge / kSplit, half = blockIdx.x % kSplit;   // the plan's index of the first window taken
-    const WalkSeg ws = wdesc[b >> kWalkHintShift];
-    const uint32_t w = b - ws.wg_base;                            // a multiple of kMerge: chunks start on multiples of 8
-    if (w >= ws.nw) return;                                       // padding
-    if (ws.upw != 0) {
-        // the wavefront index is uniform: telling the compiler so keeps all the row geometry in scalar registers
-        const uint32_t lane = tid & (kRowsLanes - 1), wave = __builtin_amdgcn_readfirstlane(tid / kRowsLanes);
-
-        // this window's slice of correctors: entry j = corrector of column 256 w + j - kWalkPad; in table mode it comes
-        // from the plan-time table, 16 bytes per thread, requested before the samples
-        constexpr uint32_t kEntries = WalkVec<IN_FMT, OUT_FMT>::kEntries;
-        constexpr int TL = ((int)kEntries / 2 + THREADS - 1) / THREADS;     // 16-byte pieces per thread: 1
-        // Where the slice comes from is decided per matrix by the planner (WalkSeg::tab_off): evaluated here by the
-        // workgroup (no table, no table traffic: matrices of few rows, whose table entries would each be used only a few
-        // times), or read from the plan-time table (matrices of many rows: the table is fetched from HBM by the first
-        // chunk and found in the L2 by the others, and costs no arithmetic).
-        const bool compute = ws.tab_off == kWalkNoTable;
-        float2 t0[TL], t1[TL];
-        if (!compute) {
-            const float2 *tab = lut_pool + ws.tab_off + w * kWalkWindow + half * WalkVec<IN_FMT, OUT_FMT>::kCols;
-#pragma unroll
-            for (int i = 0; i < TL; ++i) {
-                const uint32_t j = tid + (uint32_t)i * THREADS;
-                if (j < kEntries / 2) {
-                    t0[i] = tab[2 * j];
-                    t1[i] = tab[2 * j + 1];
-                }
-            }
-        }
-        // rows per wavefront of this chunk: uniform for the workgroup
-        switch (ws.upw) {
-        case 1:  walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 1, TL>(in, out, sink, ws, w, half, wave, lane, tid, compute, t0, t1, slice, xpose); break;
-        case 2:  walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 2, TL>(in, out, sink, ws, w, half, wave, lane, tid, compute, t0, t1, slice, xpose); break;
-        case 3:  walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 3, TL>(in, out, sink, ws, w, half, wave, lane, tid, compute, t0, t1, slice, xpose); break;
-        default: walk_rows<IN_FMT, OUT_FMT, FMA, WAVES, 4, TL>(in, out, sink, ws, w, half, wave, lane, tid, compute, t0, t1, slice, xpose); break;
-        }
-    } else {
-        // ---- leftover ranges: one block of kLeftBlock samples of ONE stretch, sincos per sample
-        if (half != 0) return;                                    // a leftover block is one workgroup whatever the grid scaling
-        for (uint32_t wi = w; wi < w + kMerge && wi < ws.nw; ++wi)   // (kMerge blocks, one after the other, where windows are merged)
-            leftover_block<IN_FMT, OUT_FMT, FMA, THREADS>(in, out, left, lhint, segs, ws.row0 + wi, tid);
-    }
-}
-
 // one block of kLeftBlock samples of ONE stretch, sincos per sample (lead-ins, heads, tails, stretches too short for a matrix)
 template <int IN_FMT, int OUT_FMT, bool FMA, int THREADS>
 __device__ __forceinline__ void leftover_block(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const LeftRange *__restrict__ left,
-                                               const uint32_t *__restrict__ lhint, const DevSeg *__restrict__ segs, uint32_t e, uint32_t tid)
+                                               const uint32_t *__restrict__ lhint, const DevSeg *__restrict__ segs, uint32_t e, uint32_t tid, bool legacy)
 {
     {
         // e: index of this block among all leftover blocks
@@ -812,13 +602,14 @@ __device__ __forceinline__ void leftover_block(const uint8_t *__restrict__ in, u
 #pragma unroll
             for (int i = 0; i < Fmt<IN_FMT>::kVecs; ++i) qi.v[i] = qv[i];
             Quad<OUT_FMT> qo;
+            float re[4], im[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float a, bq, re, im;
+                float a, bq;
                 quad_get<IN_FMT, kRawI16<IN_FMT, OUT_FMT>>(qi, k, a, bq);
-                mix(a, bq, cs[k].x, cs[k].y, re, im);
-                quad_set<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(qo, k, re, im);
+                mix(a, bq, cs[k].x, cs[k].y, re[k], im[k]);
             }
+            quad_set4<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(qo, re, im, legacy);
 #pragma unroll
             for (int i = 0; i < Fmt<OUT_FMT>::kVecs; ++i) {
                 const u32x4_u o = qo.v[i];
@@ -852,7 +643,7 @@ __device__ __forceinline__ void leftover_block(const uint8_t *__restrict__ in, u
                 float a, bq, re, im;
                 load_one<IN_FMT, kRawI16<IN_FMT, OUT_FMT>>(in, g0 + o, a, bq);
                 mix(a, bq, cs[k].x, cs[k].y, re, im);
-                store_one<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(out, g0 + o, re, im);
+                store_one<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(out, g0 + o, re, im, legacy);
             }
         }
         }
@@ -895,7 +686,12 @@ __device__ __forceinline__ RowGeo row_geo(const WalkSeg &ws, uint32_t r)
     return g;
 }
 
-constexpr int kSpanU = 2;     // rows a wavefront takes per turn
+// slice entries a workgroup may hold: one window (+ the row shifts), or up to four adjacent windows (MULTI: the
+// launches whose spans come from descriptors, dpx_types.h WalkSeg::wshift)
+template <int IN_FMT, int OUT_FMT, bool MULTI> struct SpanSlice {
+    static constexpr uint32_t kCols = WalkVec<IN_FMT, OUT_FMT>::kCols;
+    static constexpr uint32_t kEntries = (MULTI ? kCols << kSpanMaxShift : kCols) + kWalkPad;
+};
 
 template <int IN_FMT, int OUT_FMT>
 struct SpanTypes {
@@ -923,17 +719,17 @@ __device__ __forceinline__ void span_load_row(const uint8_t *__restrict__ in, co
 }
 
 // mix one row with the slice and store it
-template <int IN_FMT, int OUT_FMT, bool FULL>
+template <int IN_FMT, int OUT_FMT, bool FULL, bool MULTI>
 __device__ __forceinline__ void span_finish_row(uint8_t *__restrict__ out, const RowGeo &g, uint32_t col0, uint32_t lane,
                                                 const typename SpanTypes<IN_FMT, OUT_FMT>::qvec (&q)[SpanTypes<IN_FMT, OUT_FMT>::NV],
-                                                const float2 *slice, uint32_t *xrow)
+                                                const float2 *slice, uint32_t *xrow, bool legacy)
 {
     typedef SpanTypes<IN_FMT, OUT_FMT> T;
     constexpr int S = T::S, NV = T::NV;
     constexpr int OB = Fmt<OUT_FMT>::kBytes;
     constexpr bool XP = T::WV::kTranspose;
     constexpr bool RAW = kRawI16<IN_FMT, OUT_FMT>;
-    typedef SlicePlanes<S, T::WV::kEntries> SP;
+    typedef SlicePlanes<S, SpanSlice<IN_FMT, OUT_FMT, MULTI>::kEntries> SP;
     uint8_t *rowo = out + g.row0 * OB;                             // uniform
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -950,19 +746,17 @@ __device__ __forceinline__ void span_finish_row(uint8_t *__restrict__ out, const
         }
         const bool active = FULL || c < g.rowlen;
         if constexpr (OUT_FMT == DPX_FMT_I16) {
+            uint32_t pk[S];
+            pack_row<RAW, S>(re, im, pk, legacy);
             if constexpr (S == 4) {
-                u32x4 o = {pack_i16<RAW>(re[0], im[0]), pack_i16<RAW>(re[1], im[1]), pack_i16<RAW>(re[2], im[2]), pack_i16<RAW>(re[3], im[3])};
+                u32x4 o = {pk[0], pk[1], pk[2], pk[3]};
                 asm volatile("" : "+v"(o));   // keeps the vectoriser from rebuilding the store without its nt flag
                 if (active) __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(rowo + c * OB));
             } else if constexpr (XP) {
-                u32x2 o;
-                o[0] = pack_i16<RAW>(re[0], im[0]);
-                o[1] = pack_i16<RAW>(re[1], im[1]);
+                const u32x2 o = {pk[0], pk[1]};
                 *reinterpret_cast<u32x2 *>(xrow + (uint32_t)v * (kRowsLanes * S) + lane * S) = o;
             } else {
-                u32x2 o;
-                o[0] = pack_i16<RAW>(re[0], im[0]);
-                o[1] = pack_i16<RAW>(re[1], im[1]);
+                const u32x2 o = {pk[0], pk[1]};
                 if (active) __builtin_nontemporal_store(o, reinterpret_cast<u32x2 *>(rowo + c * OB));
             }
         } else {
@@ -986,21 +780,34 @@ __device__ __forceinline__ void span_finish_row(uint8_t *__restrict__ out, const
     }
 }
 
-template <int IN_FMT, int OUT_FMT, bool FMA, int WAVES>
+// U: rows a wavefront takes per turn.  MULTI: the span's workgroups take 2^ws.wshift adjacent windows, WAVES >> wshift
+// wavefronts each (a wave-uniform split: everything below stays in scalar registers); `g.off` of a row then counts from
+// the first of them, sub * kCols entries further for the wavefronts of window `sub`.
+template <int IN_FMT, int OUT_FMT, bool FMA, int WAVES, int U, bool MULTI>
 __device__ __forceinline__ void span_body(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const WalkSeg &ws,
                                           uint32_t w, uint32_t half, uint32_t wave, uint32_t lane, uint32_t tid,
-                                          float2 *slice, uint32_t *xpose)
+                                          float2 *slice, uint32_t *xpose, bool legacy)
 {
     typedef SpanTypes<IN_FMT, OUT_FMT> T;
     typedef typename T::WV WV;
-    constexpr int U = kSpanU, NV = T::NV;
+    constexpr int NV = T::NV;
     constexpr int THREADS = WAVES * 64;
-    constexpr uint32_t kEntries = WV::kEntries;                  // 288, or 160 for half a window
-    typedef SlicePlanes<T::S, kEntries> SP;
-    const uint32_t col0 = w * kWalkWindow + half * WV::kCols;    // first column of this workgroup
-    const uint32_t stride = WAVES * U;
+    constexpr uint32_t kCols = WV::kCols, kSplit = WV::kSplit;
+    typedef SlicePlanes<T::S, SpanSlice<IN_FMT, OUT_FMT, MULTI>::kEntries> SP;
+    // the workgroup's windows, and this wavefront's place among them
+    const uint32_t wshift = MULTI ? ws.wshift : 0u;                   // uniform
+    uint32_t sub = 0, wiw = wave, wpwin = WAVES;                       // window of the workgroup, wavefront of the window, wavefronts per window
+    if (MULTI && wshift != 0) {
+        wpwin = (uint32_t)WAVES >> wshift;
+        sub = wave / wpwin;                                            // scalar: WAVES and wshift are tiny
+        wiw = wave - sub * wpwin;
+    }
+    const uint32_t colbase = ((w * kSplit + half) << wshift) * kCols;  // first column of this workgroup
+    const uint32_t col0 = colbase + sub * kCols;                       // ... and of this wavefront
+    const uint32_t n_entries = (kCols << wshift) + kWalkPad;           // the workgroup's slice
+    const uint32_t stride = wpwin * U;
 
-    uint32_t r = ws.row0 + wave * U;                             // this wavefront's rows: r, r + 1, then r + stride ...
+    uint32_t r = ws.row0 + wiw * U;                              // this wavefront's rows: r .. r + U - 1, then r + stride ...
     typename T::qvec q[U][NV];
     auto request = [&](uint32_t rr) {
 #pragma unroll
@@ -1008,29 +815,30 @@ __device__ __forceinline__ void span_body(const uint8_t *__restrict__ in, uint8_
             if (rr + u < ws.row_end) {                           // uniform
                 const RowGeo g = row_geo(ws, rr + u);
                 if (col0 >= g.rowlen) continue;                  // the matrix's last row ends before this window
-                if (col0 + WV::kCols <= g.rowlen) span_load_row<IN_FMT, OUT_FMT, true>(in, g, col0, lane, q[u]);
-                else                              span_load_row<IN_FMT, OUT_FMT, false>(in, g, col0, lane, q[u]);
+                if (col0 + kCols <= g.rowlen) span_load_row<IN_FMT, OUT_FMT, true>(in, g, col0, lane, q[u]);
+                else                          span_load_row<IN_FMT, OUT_FMT, false>(in, g, col0, lane, q[u]);
             }
         }
     };
     request(r);
 
-    // the slice: thread j evaluates entry j (the first 32 threads also entry 256 + j) with the bit-exact sincos, after the
-    // first rows' loads have been issued; entry j = corrector of column col0 + j - kWalkPad
+    // the slice: thread j evaluates entry j, j + THREADS, ... with the bit-exact sincos, after the first rows' loads have
+    // been issued; entry j = corrector of column colbase + j - kWalkPad
     {
         const uint32_t P = ws.period;
-        // counter of entry j, minus one: (phase + col0 + j - kWalkPad) mod P.  The part that does not depend on j is
-        // reduced once (uniform; rows are multiples of the period, so col0 may exceed it many times), entry by entry
+        // counter of entry j, minus one: (phase + colbase + j - kWalkPad) mod P.  The part that does not depend on j is
+        // reduced once (uniform; rows are multiples of the period, so colbase may exceed it many times), entry by entry
         // one conditional subtraction is left — periods shorter than a slice take the modulo per entry.
-        const uint32_t ub = (ws.phase + col0 + P * kWalkPad - kWalkPad) % P;     // 32-bit: phase < P, col0 <= L, P <= 2^22 (kLutMaxEntries)
-        constexpr int kRounds = ((int)kEntries + THREADS - 1) / THREADS;
+        const uint32_t ub = (ws.phase + colbase + P * kWalkPad - kWalkPad) % P;  // 32-bit: phase < P, colbase <= L + 1024, P <= 2^22 (kLutMaxEntries)
+        constexpr int kRounds = ((int)SpanSlice<IN_FMT, OUT_FMT, MULTI>::kEntries + THREADS - 1) / THREADS;
 #pragma unroll
         for (int it = 0; it < kRounds; ++it) {
+            if (MULTI && (uint32_t)it * THREADS >= n_entries) break;             // uniform
             const uint32_t j = tid + (uint32_t)it * THREADS;
-            if (j < kEntries) {
+            if (j < n_entries) {
                 uint32_t t = ub + j;
-                if (P > kEntries) t = t >= P ? t - P : t;        // uniform: j < kEntries < P
-                else              t %= P;
+                if (P > n_entries) t = t >= P ? t - P : t;       // uniform: j < n_entries < P
+                else               t %= P;
                 float c, sn;
                 corrector<FMA>(ws.ratio, t + 1u, c, sn);
                 slice[SP::index(j)] = make_float2(c, sn);
@@ -1039,6 +847,7 @@ __device__ __forceinline__ void span_body(const uint8_t *__restrict__ in, uint8_
     }
     __syncthreads();
 
+    const float2 *wslice = slice + sub * (kCols / T::S);           // entry e of this window = entry e + sub * kCols of the slice
     while (r < ws.row_end) {                                     // uniform per wavefront
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1046,8 +855,8 @@ __device__ __forceinline__ void span_body(const uint8_t *__restrict__ in, uint8_
                 const RowGeo g = row_geo(ws, r + u);
                 if (col0 >= g.rowlen) continue;
                 uint32_t *xrow = xpose + (wave * U + u) * kWalkWindow;
-                if (col0 + WV::kCols <= g.rowlen) span_finish_row<IN_FMT, OUT_FMT, true>(out, g, col0, lane, q[u], slice, xrow);
-                else                              span_finish_row<IN_FMT, OUT_FMT, false>(out, g, col0, lane, q[u], slice, xrow);
+                if (col0 + kCols <= g.rowlen) span_finish_row<IN_FMT, OUT_FMT, true, MULTI>(out, g, col0, lane, q[u], wslice, xrow, legacy);
+                else                          span_finish_row<IN_FMT, OUT_FMT, false, MULTI>(out, g, col0, lane, q[u], wslice, xrow, legacy);
             }
         }
         r += stride;
@@ -1063,6 +872,7 @@ __global__ __launch_bounds__(WAVES * 64) void span_kernel(const uint8_t *__restr
                                                             WalkUni uni,                           // UNI only
                                                             const WalkSeg *__restrict__ wdesc,     // !UNI only
                                                             uint32_t n_left_wg,
+                                                            uint32_t cast_legacy,                  // dpx_set_i16_cast
                                                             // ---- leftover path only
                                                             const LeftRange *__restrict__ left,
                                                             const uint32_t *__restrict__ lhint,
@@ -1071,12 +881,16 @@ __global__ __launch_bounds__(WAVES * 64) void span_kernel(const uint8_t *__restr
     constexpr int S = WalkVec<IN_FMT, OUT_FMT>::S;
     constexpr int THREADS = WAVES * 64;
     constexpr bool XP = WalkVec<IN_FMT, OUT_FMT>::kTranspose;
-    typedef SlicePlanes<S, WalkVec<IN_FMT, OUT_FMT>::kEntries> SPK;
+    constexpr bool MULTI = !UNI;                                  // spans from descriptors may take several windows per workgroup
+    constexpr int kMaxU = 2;                                      // rows per wavefront per turn
+    typedef SlicePlanes<S, SpanSlice<IN_FMT, OUT_FMT, MULTI>::kEntries> SPK;
     __shared__ float2 slice[SPK::kPlanes * SPK::kStride];
-    __shared__ __attribute__((aligned(16))) uint32_t xpose[XP ? WAVES * kSpanU * (int)kWalkWindow : 4];   // packed i16 samples of one row per (wavefront, u); read back as 16-byte vectors
+    __shared__ __attribute__((aligned(16))) uint32_t xpose[XP ? WAVES * kMaxU * (int)kWalkWindow : 4];   // packed i16 samples of one row per (wavefront, u); read back as 16-byte vectors
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t kSplit = WalkVec<IN_FMT, OUT_FMT>::kSplit;
+    static_assert(kSplit == span_split(IN_FMT, OUT_FMT), "the planner's simulation walks the same grid");
     const uint32_t half = blockIdx.x % kSplit;
+    const bool legacy = cast_legacy != 0;                         // uniform
     if constexpr (UNI) {
         const uint32_t w = blockIdx.x / kSplit, c = blockIdx.y;
         if (c < uni.n_spans) {
@@ -1085,24 +899,28 @@ __global__ __launch_bounds__(WAVES * 64) void span_kernel(const uint8_t *__restr
             ws.row0 = c * uni.base + (c < uni.rem ? c : uni.rem);
             ws.row_end = ws.row0 + uni.base + (c < uni.rem ? 1u : 0u);
             const uint32_t lane = tid & (kRowsLanes - 1), wave = __builtin_amdgcn_readfirstlane(tid / kRowsLanes);
-            span_body<IN_FMT, OUT_FMT, FMA, WAVES>(in, out, ws, w, half, wave, lane, tid, slice, xpose);
+            span_body<IN_FMT, OUT_FMT, FMA, WAVES, 2, false>(in, out, ws, w, half, wave, lane, tid, slice, xpose, legacy);
         } else {
             const uint32_t e = (c - uni.n_spans) * uni.nw8 + w;   // leftover block
             if (half != 0 || e >= n_left_wg) return;
-            leftover_block<IN_FMT, OUT_FMT, FMA, THREADS>(in, out, left, lhint, segs, e, tid);
+            leftover_block<IN_FMT, OUT_FMT, FMA, THREADS>(in, out, left, lhint, segs, e, tid, legacy);
         }
     } else {
-        // the descriptor of this group of 8 workgroups (as in the walk kernel): a span of a matrix, or a group of leftover blocks
+        // ONE scalar load before the first sample load: the descriptor of this group of 8 workgroups — a span of a matrix
+        // (replicated per group; spans start on multiples of 8 workgroups) or a group of leftover blocks.  The leftover
+        // groups (sincos per sample, VALU-bound) are spread evenly between the spans by the planner, so that they run
+        // beside memory-bound workgroups.
         const uint32_t b = blockIdx.x / kSplit;
         const WalkSeg ws = wdesc[b >> kWalkHintShift];
         const uint32_t w = b - ws.wg_base;
-        if (w >= ws.nw) return;                                   // padding
+        if (w >= ws.nwg) return;                                  // padding
         if (ws.upw != 0) {
+            // the wavefront index is uniform: telling the compiler so keeps all the row geometry in scalar registers
             const uint32_t lane = tid & (kRowsLanes - 1), wave = __builtin_amdgcn_readfirstlane(tid / kRowsLanes);
-            span_body<IN_FMT, OUT_FMT, FMA, WAVES>(in, out, ws, w, half, wave, lane, tid, slice, xpose);
+            span_body<IN_FMT, OUT_FMT, FMA, WAVES, 2, true>(in, out, ws, w, half, wave, lane, tid, slice, xpose, legacy);
         } else {
             if (half != 0) return;                                // a leftover block is one workgroup whatever the grid scaling
-            leftover_block<IN_FMT, OUT_FMT, FMA, THREADS>(in, out, left, lhint, segs, ws.row0 + w, tid);
+            leftover_block<IN_FMT, OUT_FMT, FMA, THREADS>(in, out, left, lhint, segs, ws.row0 + w, tid, legacy);
         }
     }
 }
@@ -1188,27 +1006,24 @@ __global__ __launch_bounds__(kBlock) void ccexpf_kernel(float2 *__restrict__ z, 
 
 template <int IN_FMT, int OUT_FMT>
 static int tiles_t(const void *d_in, void *d_out, const DevSeg *d_segs, uint32_t n_segs,
-                   const uint32_t *d_hint, const void *d_lut, const TileArgs &t, bool fma,
+                   const uint32_t *d_hint, const void *d_lut, const TileArgs &t_in, bool fma,
                    const LaunchGeom &g, hipStream_t st)
 {
+    TileArgs t = t_in;
+    t.legacy = (g.legacy_cast && OUT_FMT == DPX_FMT_I16) ? 1u : 0u;
     const uint8_t *in = static_cast<const uint8_t *>(d_in);
     uint8_t *out = static_cast<uint8_t *>(d_out);
     const float2 *lut = static_cast<const float2 *>(d_lut);
     if (t.n_tiles == 0) return DPX_OK;
     if (t.n_tiles > 0x7fffffffull) return DPX_ERR_ARG;
     const dim3 grid((uint32_t)t.n_tiles);
-    if (g.legacy_cast && OUT_FMT == DPX_FMT_I16) {      // the 2016 meaning of `as i16`: one geometry, tile kernel only
-        if (fma) tile_kernel<IN_FMT, OUT_FMT, true, 256, 1, true><<<grid, 256, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t);
-        else     tile_kernel<IN_FMT, OUT_FMT, false, 256, 1, true><<<grid, 256, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t);
-        return g.tile() == 1024u && hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;
-    }
 #define DPX_CASE(B, Vv)                                                                                      \
     if (g.block == B && g.vecs == Vv) {                                                                      \
         if (fma) tile_kernel<IN_FMT, OUT_FMT, true, B, Vv><<<grid, B, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t);  \
         else     tile_kernel<IN_FMT, OUT_FMT, false, B, Vv><<<grid, B, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t); \
         return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                       \
     }
-    DPX_CASE(128, 1) DPX_CASE(128, 2) DPX_CASE(256, 1) DPX_CASE(256, 2)
+    DPX_CASE(128, 2) DPX_CASE(256, 1)
 #undef DPX_CASE
     return DPX_ERR_ARG;
 }
@@ -1223,7 +1038,7 @@ int launch_tiles(const void *d_in, int in_fmt, void *d_out, int out_fmt, const D
 
 template <int IN_FMT, int OUT_FMT>
 static int rows_t(const void *d_in, void *d_out, const DevSeg *d_segs, const void *d_lut,
-                  const RowsArgs &r, bool fma, hipStream_t st)
+                  const RowsArgs &r, bool fma, int legacy_cast, hipStream_t st)
 {
     const uint8_t *in = static_cast<const uint8_t *>(d_in);
     uint8_t *out = static_cast<uint8_t *>(d_out);
@@ -1238,8 +1053,8 @@ static int rows_t(const void *d_in, void *d_out, const DevSeg *d_segs, const voi
     // exact b / cols for b < 2^31: M = ceil(2^(31+s) / cols), s = ceil(log2 cols)
     uint32_t s = 0;
     while ((1u << s) < cols) ++s;
-    const uint32_t sh = 31 + s;
-    const uint64_t M = ((1ull << sh) + cols - 1) / cols;
+    const uint32_t sh = (31 + s) | ((legacy_cast && OUT_FMT == DPX_FMT_I16) ? 0x80000000u : 0u);   // bit 31: the legacy i16 cast
+    const uint64_t M = ((1ull << (31 + s)) + cols - 1) / cols;
     const dim3 grid((uint32_t)(n_main + n_extra));
     const float2 *tab = lut + r.tab_off;
     // table or evaluation: the plan allows both for long periods, the formats decide (dpx_planner.cpp, kRowsComputeMinP)
@@ -1256,86 +1071,48 @@ static int rows_t(const void *d_in, void *d_out, const DevSeg *d_segs, const voi
 }
 
 int launch_rows(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,
-                const void *d_lut, const RowsArgs &r, bool fma, void *stream)
+                const void *d_lut, const RowsArgs &r, bool fma, int legacy_cast, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    DPX_DISPATCH_FMT(rows_t, d_in, d_out, d_segs, d_lut, r, fma, st);
+    DPX_DISPATCH_FMT(rows_t, d_in, d_out, d_segs, d_lut, r, fma, legacy_cast, st);
 }
 
 template <int IN_FMT, int OUT_FMT>
-static int walk_t(const void *d_in, void *d_out, const DevSeg *d_segs, const void *d_lut, const WalkSeg *d_wdesc,
-                  const LeftRange *d_left, const uint32_t *d_lhint, void *d_sink, const WalkArgs &w, bool fma, hipStream_t st)
+static int span_t(const void *d_in, void *d_out, const DevSeg *d_segs, const WalkSeg *d_wdesc,
+                  const LeftRange *d_left, const uint32_t *d_lhint, const WalkArgs &w, bool fma, int legacy_cast, hipStream_t st)
 {
+    const uint32_t lg = (legacy_cast && OUT_FMT == DPX_FMT_I16) ? 1u : 0u;
     const uint8_t *in = static_cast<const uint8_t *>(d_in);
     uint8_t *out = static_cast<uint8_t *>(d_out);
-    uint8_t *sink = static_cast<uint8_t *>(d_sink);
-    const float2 *lut = static_cast<const float2 *>(d_lut);
-    // the whole grid: row chunks and the groups of leftover blocks between them; x2 where a window is shared by two workgroups
-    const uint64_t n_wg = (uint64_t)w.n_walk_wg * WalkVec<IN_FMT, OUT_FMT>::kSplit / WalkVec<IN_FMT, OUT_FMT>::kMerge;
+    constexpr uint32_t kSplit = WalkVec<IN_FMT, OUT_FMT>::kSplit;
+    // the whole grid: spans and the groups of leftover blocks between them; x2 where a window is shared by two workgroups
+    const uint64_t n_wg = (uint64_t)w.n_walk_wg * kSplit;
     if (n_wg == 0) return DPX_OK;
-    if (n_wg > 0x7fffffffull) return DPX_ERR_ARG;
+    if (n_wg > 0x7fffffffull || w.span == 0) return DPX_ERR_ARG;
     const dim3 grid((uint32_t)n_wg);
-    if (w.span != 0) {
-        constexpr uint32_t kSplit = WalkVec<IN_FMT, OUT_FMT>::kSplit;
-        const bool uni = w.uni.n_spans != 0;
-        WalkUni u = w.uni;
-        uint32_t waves = w.waves;
-        // one matrix: windows along x, spans along y, then the rows of the grid that hold the leftover blocks
-        const uint32_t left_rows = uni ? (w.n_left_wg + u.nw8 - 1) / u.nw8 : 0;
-        // The spans of a one-matrix launch follow from its arguments, so the LAUNCH may cut them differently for its format
-        // pair (the plan does not know the formats).  Every pair with an f32 side wants half the rows per workgroup in const
-        // mode, each under its own number of wavefronts (the ones without rows still share the slice) — spans of 4 against
-        // the plan's spans of 8, four shifts, two processes each (`tools/ab.py --set pairs3 / pairs4`, profiles/r03_walk.md):
-        //   f32 -> f32, 4 wavefronts: 82-83 % against 75-77;   f32 -> i16, 5 wavefronts: 80-83.7 against 75-77;
-        //   i16 -> f32, 2 wavefronts: 77-78.6 against 74-76 (68 under 4);   i16 -> i16 keeps 4 x 8 (spans of 4: 57-72).
-        // Track-shaped plans gain nothing measurable from it.  Not when the caller fixed a shape (w.auto_shape).
-        if (uni && w.auto_shape && (IN_FMT == DPX_FMT_F32 || OUT_FMT == DPX_FMT_F32) && u.seg.rows > kSpanWhole) {
-            const uint32_t k = (u.seg.rows + 3) / 4;
-            if (k + left_rows <= 65535u) {
-                u.n_spans = k;
-                u.base = u.seg.rows / k;
-                u.rem = u.seg.rows % k;
-                waves = OUT_FMT == DPX_FMT_I16 ? 5 : IN_FMT == DPX_FMT_F32 ? 4 : 2;
-            }
-        }
-        // The descriptors of a many-matrix launch fix the spans, not the workgroup size: f32 -> i16 (two 16-byte loads per
-        // lane per row) ran its replays 1.5-2 points faster under 8 wavefronts on two boxes (77.2 -> 78.8, 76.6 -> 78.9 %) and
-        // the same within that pair's run-to-run spread on a third; the other pairs lose under more than 4 (i16 -> f32 73.8 -> 61.4)
-        if (!uni && w.auto_shape && IN_FMT == DPX_FMT_F32 && OUT_FMT == DPX_FMT_I16) waves = 8;
-        const dim3 ugrid(uni ? u.nw8 * kSplit : 1, uni ? u.n_spans + left_rows : 1);
-        if (uni && ugrid.y > 65535u) return DPX_ERR_ARG;
-#define DPX_SPAN_CASE(WW)                                                                                                              \
-        if (waves == WW) {                                                                                                             \
-            if (uni) {                                                                                                                 \
-                if (fma) span_kernel<IN_FMT, OUT_FMT, true, WW, true><<<ugrid, WW * 64, 0, st>>>(in, out, u, d_wdesc, w.n_left_wg, d_left, d_lhint, d_segs);   \
-                else     span_kernel<IN_FMT, OUT_FMT, false, WW, true><<<ugrid, WW * 64, 0, st>>>(in, out, u, d_wdesc, w.n_left_wg, d_left, d_lhint, d_segs);  \
-            } else {                                                                                                                   \
-                if (fma) span_kernel<IN_FMT, OUT_FMT, true, WW, false><<<grid, WW * 64, 0, st>>>(in, out, w.uni, d_wdesc, w.n_left_wg, d_left, d_lhint, d_segs);   \
-                else     span_kernel<IN_FMT, OUT_FMT, false, WW, false><<<grid, WW * 64, 0, st>>>(in, out, w.uni, d_wdesc, w.n_left_wg, d_left, d_lhint, d_segs);  \
-            }                                                                                                                          \
-            return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                                             \
-        }
-        DPX_SPAN_CASE(4) DPX_SPAN_CASE(5) DPX_SPAN_CASE(8) DPX_SPAN_CASE(2)
-#undef DPX_SPAN_CASE
-        return DPX_ERR_ARG;
-    }
-#define DPX_WALK_CASE(WW)                                                                                                              \
-    if (w.waves == WW) {                                                                                                               \
-        if (fma) walk_kernel<IN_FMT, OUT_FMT, true, WW><<<grid, WW * 64, 0, st>>>(in, out, lut, d_wdesc, w.n_left_wg, sink, d_left, d_lhint, d_segs);  \
-        else     walk_kernel<IN_FMT, OUT_FMT, false, WW><<<grid, WW * 64, 0, st>>>(in, out, lut, d_wdesc, w.n_left_wg, sink, d_left, d_lhint, d_segs); \
+    // what this format pair makes of the plan's shape (dpx_planner.cpp: the same function the planner's simulation walks)
+    SpanLaunch sl;
+    if (!span_launch_shape(w, IN_FMT, OUT_FMT, &sl)) return DPX_ERR_ARG;
+    const bool uni = sl.uni.n_spans != 0;
+    const dim3 ugrid(uni ? sl.uni.nw8 * kSplit : 1, uni ? sl.uni.n_spans + sl.left_rows : 1);
+#define DPX_SPAN_CASE(WW, UU)                                                                                                          \
+    if (sl.waves == WW && uni == UU) {                                                                                                 \
+        if (fma) span_kernel<IN_FMT, OUT_FMT, true, WW, UU><<<UU ? ugrid : grid, WW * 64, 0, st>>>(in, out, sl.uni, d_wdesc, w.n_left_wg, lg, d_left, d_lhint, d_segs);   \
+        else     span_kernel<IN_FMT, OUT_FMT, false, WW, UU><<<UU ? ugrid : grid, WW * 64, 0, st>>>(in, out, sl.uni, d_wdesc, w.n_left_wg, lg, d_left, d_lhint, d_segs);  \
         return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                                                 \
     }
-    DPX_WALK_CASE(5) DPX_WALK_CASE(4) DPX_WALK_CASE(6) DPX_WALK_CASE(8) DPX_WALK_CASE(3) DPX_WALK_CASE(2)
-#undef DPX_WALK_CASE
+    DPX_SPAN_CASE(4, true) DPX_SPAN_CASE(4, false) DPX_SPAN_CASE(5, true) DPX_SPAN_CASE(2, true) DPX_SPAN_CASE(8, false)
+    DPX_SPAN_CASE(5, false) DPX_SPAN_CASE(2, false)
+#undef DPX_SPAN_CASE
     return DPX_ERR_ARG;
 }
 
-int launch_walk(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs, const void *d_lut,
-                const WalkSeg *d_walk_desc, const LeftRange *d_left, const uint32_t *d_left_hint, void *d_sink,
-                const WalkArgs &w, bool fma, void *stream)
+int launch_span(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,
+                const WalkSeg *d_walk_desc, const LeftRange *d_left, const uint32_t *d_left_hint,
+                const WalkArgs &w, bool fma, int legacy_cast, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    DPX_DISPATCH_FMT(walk_t, d_in, d_out, d_segs, d_lut, d_walk_desc, d_left, d_left_hint, d_sink, w, fma, st);
+    DPX_DISPATCH_FMT(span_t, d_in, d_out, d_segs, d_walk_desc, d_left, d_left_hint, w, fma, legacy_cast, st);
 }
 
 int launch_build_lut(void *d_lut_entries, uint32_t period, uint32_t n_first, uint32_t n_entries,

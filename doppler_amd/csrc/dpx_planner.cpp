@@ -343,27 +343,34 @@ uint32_t pick_rows_per_wave(uint32_t P, const PlanTuning &tn, uint32_t compute)
 
 struct Interval { uint64_t lo, hi; };
 
-// walk kernel: a matrix with at least this many rows gets a plan-time table (each entry is then used that many times:
-// little traffic, no arithmetic); the workgroups of shorter matrices evaluate their slices themselves (profiles/r02_walk.md)
-constexpr uint32_t kWalkTableRows = 0xffffffffu;   // never: evaluating the slices measured at least as fast on every plan shape tried
 constexpr uint64_t kWalkTileMinDefault = 1ull << 22;   // an uncovered gap at least this long gets its own tile launch ...
 constexpr size_t kWalkMaxTileLaunches = 8;       // ... up to this many; the rest is evaluated by leftover workgroups
 
-struct WalkShape { uint32_t waves, rows_per_wave, span; };
-// span != 0: the span kernel (a workgroup keeps its window for up to `span` rows, two per wavefront per turn);
-// span == 0: the walk kernel (chunks of waves x rows_per_wave rows).  Plans that ask for tables are walk plans.
+struct WalkShape { uint32_t waves, span; bool fixed; };
+// waves: wavefronts per workgroup; span: most rows per span; fixed: the caller named a span height (measurement): spans of
+// exactly that cut, one window per workgroup, two rows per wavefront per turn
 WalkShape walk_shape(const PlanTuning &tn)
 {
-    WalkShape g = {kWalkWaves, kWalkRowsPerWave, 0};
-    if (tn.walk_waves) g.waves = tn.walk_waves;                                // measurement overrides
-    if (tn.walk_rows) g.rows_per_wave = std::min(tn.walk_rows, kWalkMaxRowsPerWave);
-    const bool tables = tn.walk_compute == 0 || (tn.walk_compute < 0 && tn.walk_table_rows != 0);
-    if (tn.walk_span != 1 && !tables) {
-        g.span = tn.walk_span ? tn.walk_span : kSpanRows;
-        g.rows_per_wave = 2;
-        if (!(g.waves == 2 || g.waves == 4 || g.waves == 5 || g.waves == 8)) g.waves = kSpanWaves;
-    }
+    WalkShape g = {kSpanWaves, kSpanRows, false};
+    if (tn.walk_waves == 2 || tn.walk_waves == 4 || tn.walk_waves == 5 || tn.walk_waves == 8) g.waves = tn.walk_waves;
+    if (tn.walk_span >= 2) { g.span = tn.walk_span; g.fixed = true; }
     return g;
+}
+
+// One span of a matrix: `h` rows under `waves` wavefronts.
+//   h <= 4 (waves = 4): the workgroup takes 2 (h <= 2: 4) adjacent windows, 2 (1) wavefronts each — otherwise half
+//     (three quarters) of its wavefronts would hold no row.  Measured on the replay's seconds of 3-4 rows: 72 -> 78 % under
+//     two wavefronts per window, 0-2 rows: 54 -> 62 % (profiles/r04_walk.md).  In general: the largest 2^s <= 4 that divides
+//     the wavefronts and leaves (waves >> s) x 2 >= h.
+struct SpanShape { uint32_t wshift, upw; };
+SpanShape span_shape(uint32_t h, const WalkShape &g)
+{
+    SpanShape sh = {0, 2};
+    if (g.fixed) return sh;
+    for (uint32_t s2 = kSpanMaxShift; s2 > 0; --s2) {
+        if (g.waves % (1u << s2) == 0 && (g.waves >> s2) * 2 >= h) { sh.wshift = s2; break; }
+    }
+    return sh;
 }
 
 // Row length of a walk / span matrix: a multiple of the period.  Measured (profiles/r03_walk.md, `tools/ab.py --set minl`,
@@ -382,7 +389,7 @@ uint64_t walk_row_length_target(uint64_t P, uint64_t target, uint64_t len)
     return P * m;
 }
 
-// matrix of the walk kernel for one stretch (dpx_types.h, WalkSeg); false if the stretch does not qualify
+// matrix of the span kernel for one stretch (dpx_types.h, WalkSeg); false if the stretch does not qualify
 bool walk_geometry(const DevSeg &s, WalkSeg *w, const PlanTuning &tn)
 {
     if (s.lut_len == 0 || s.period == 0) return false;
@@ -399,7 +406,7 @@ bool walk_geometry(const DevSeg &s, WalkSeg *w, const PlanTuning &tn)
     w->A = A;
     w->E = E;
     w->L = (uint32_t)L;
-    w->tab_off = 0;
+    w->wshift = 0;
     w->wg_base = 0;
     w->nw = (uint32_t)nw;
     w->rows = (uint32_t)rows;
@@ -409,32 +416,80 @@ bool walk_geometry(const DevSeg &s, WalkSeg *w, const PlanTuning &tn)
     w->ratio = s.ratio;
     w->upw = 0;
     w->row_end = 0;
-    w->pad = 0;
+    w->nwg = 0;
     return true;
 }
 
+// spans of a matrix: one for up to kSpanWhole rows (every one-second matrix under the row-length rule above: its slice is
+// evaluated once; replay 76.3 -> 78.0 % against spans of 8, measured), spans of 8 = one turn of 4 x 2 each for a taller
+// one (const mode: 80.1 % with 8, 79.2 with 12, 77.5 with 16)
 uint32_t walk_chunks(const WalkSeg &w, const PlanTuning &tn)
 {
     const WalkShape g = walk_shape(tn);
-    // span kernel: a matrix of up to kSpanWhole rows (every one-second matrix under the row-length rule above) is ONE span — its
-    // slice is evaluated once, the rows past the first 8 take a second turn (replay 76.3 -> 78.0 % against spans of 8, measured);
-    // a taller matrix is cut into spans of 8 = one turn each (const mode: 80.1 % with 8, 79.2 with 12, 77.5 with 16)
-    if (g.span && !tn.walk_span && w.rows <= kSpanWhole) return 1;
-    const uint32_t rpw = g.span ? g.span : g.waves * g.rows_per_wave;
-    return (uint32_t)(((uint64_t)w.rows + rpw - 1) / rpw);
+    if (!g.fixed && w.rows <= kSpanWhole) return 1;
+    return (uint32_t)(((uint64_t)w.rows + g.span - 1) / g.span);
 }
 
+// span c of k: rows [row0, row0 + h)
+inline void span_rows(const WalkSeg &w, uint32_t k, uint32_t c, uint32_t *row0, uint32_t *h)
+{
+    const uint32_t base = w.rows / k, rem = w.rows % k;
+    *row0 = c * base + std::min(c, rem);
+    *h = base + (c < rem ? 1u : 0u);
+}
+
+// workgroups of a matrix in the descriptor list: every span padded to a multiple of 8
 uint64_t walk_workgroups(const WalkSeg &w, const PlanTuning &tn)
 {
-    return (uint64_t)((w.nw + 7) & ~7u) * walk_chunks(w, tn);     // every chunk padded to a multiple of 8 workgroups
+    const WalkShape g = walk_shape(tn);
+    const uint32_t k = walk_chunks(w, tn);
+    uint64_t n = 0;
+    for (uint32_t c = 0; c < k; ++c) {
+        uint32_t row0, h;
+        span_rows(w, k, c, &row0, &h);
+        const uint32_t nwg = (w.nw + (1u << span_shape(h, g).wshift) - 1) >> span_shape(h, g).wshift;
+        n += (nwg + 7) & ~7u;
+    }
+    return n;
 }
 
 }  // namespace
 
+// What one launch makes of a plan's span shape for its format pair (dpx_types.h, SpanLaunch).
+//
+// One matrix (const mode).  Its spans follow from the kernel arguments, so the LAUNCH may cut them differently per pair.
+// Every pair with an f32 side wants half the rows per workgroup, each under its own number of wavefronts (the ones
+// without rows still share the slice) — spans of 4 against the plan's spans of 8, four shifts, two processes each
+// (`tools/ab.py --set pairs3 / pairs4`, profiles/r03_walk.md):
+//   f32 -> f32, 4 wavefronts: 82-83 % against 75-77;   f32 -> i16, 5 wavefronts: 80-83.7 against 75-77;
+//   i16 -> f32, 2 wavefronts: 77-78.6 against 74-76 (68 under 4);   i16 -> i16 keeps 4 x 8 (spans of 4: 57-72).
+// Not when the caller fixed a shape (auto_shape == 0).
+// Many matrices (track mode).  The descriptors fix the spans, not the workgroup size: f32 -> i16 (two 16-byte loads per
+// lane per row) ran its replays 1.5-2 points faster under 8 wavefronts on two boxes (77.2 -> 78.8, 76.6 -> 78.9 %); the
+// other pairs lose under more than 4 (i16 -> f32 73.8 -> 61.4).  The planner's window shifts divide 4, hence 8.
+bool span_launch_shape(const WalkArgs &w, int in_fmt, int out_fmt, SpanLaunch *o)
+{
+    const bool in_f32 = in_fmt == 1, out_f32 = out_fmt == 1;
+    o->uni = w.uni;
+    o->waves = w.waves;
+    const bool uni = w.uni.n_spans != 0;
+    o->left_rows = uni ? (w.n_left_wg + w.uni.nw8 - 1) / w.uni.nw8 : 0;
+    if (uni && w.auto_shape && (in_f32 || out_f32) && w.uni.seg.rows > kSpanWhole) {
+        const uint32_t k = (w.uni.seg.rows + 3) / 4;
+        if ((uint64_t)k + o->left_rows <= 65535u) {
+            o->uni.n_spans = k;
+            o->uni.base = w.uni.seg.rows / k;
+            o->uni.rem = w.uni.seg.rows % k;
+            o->waves = !out_f32 ? 5 : in_f32 ? 4 : 2;
+        }
+    }
+    if (!uni && w.auto_shape && in_f32 && !out_f32) o->waves = 8;
+    if (uni && (uint64_t)o->uni.n_spans + o->left_rows > 65535u) return false;
+    return o->waves == 2 || o->waves == 4 || o->waves == 5 || (o->waves == 8 && !uni);
+}
+
 void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
 {
-    // which matrices of a walk launch get a plan-time table (the others' workgroups evaluate their slices themselves)
-    const uint32_t table_rows = tn.walk_compute == 0 ? 0u : tn.walk_compute > 0 ? 0xffffffffu : (tn.walk_table_rows ? tn.walk_table_rows : kWalkTableRows);
     const uint64_t kWalkTileMin = tn.walk_tilemin ? tn.walk_tilemin : kWalkTileMinDefault;
     plan.tile = tile;
     plan.error = nullptr;
@@ -495,12 +550,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         use_walk = in_matrices > 0 && in_matrices >= plan.n_samples / 2 && n_wg < 0x40000000ull;
     }
 
-    // Workgroup shape of the walk launch: 4 wavefronts x 2 rows for track-shaped plans (a second of stream is 5-40 rows:
-    // small workgroups waste fewer wavefront slots on the partly filled chunks every such matrix ends with), 5 x 2 for
-    // the long matrices of const-mode plans (measured, profiles/r02_walk.md: replay 74.8 / 72.4 % with 4 / 5 wavefronts,
-    // const 5001 Hz 78.8 / 80.0 %).
-    PlanTuning tnw = tn;
-    if (!tnw.walk_waves) tnw.walk_waves = walk_shape(tn).span ? kSpanWaves : use_walk ? kWalkWavesTrack : kWalkWaves;
+    const PlanTuning &tnw = tn;
 
     // Const-mode plans: a stretch whose period does not allow rows of whole 4 KiB pages (odd periods: the common case
     // for an arbitrary integer --shift) runs 4-23 % faster as a walk-kernel matrix than as a rows launch with
@@ -613,17 +663,6 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
                 continue;
             }
             s.flags |= kSegWalk;
-            w.tab_off = kWalkNoTable;
-            if (w.rows >= table_rows) {
-                // entry x = corrector of column x - kWalkPad, column 0 = sample A
-                w.tab_off = (uint32_t)pool;
-                const uint32_t P = s.period;
-                const uint32_t n_first = (uint32_t)(((uint64_t)w.phase + (uint64_t)P * kWalkPad - kWalkPad) % P) + 1u;
-                // every window reads a whole slice; one window more, because an i16 -> i16 workgroup takes two windows at once
-                const uint32_t n_entries = (w.nw + 1) * kWalkWindow + kWalkPad;
-                plan.tables.push_back({pool, P, n_first, n_entries, s.ratio});
-                pool += ((uint64_t)n_entries + 3) & ~3ull;
-            }
             mats.push_back(w);
             if (s.first < w.A) uncovered(s.first, w.A, (uint32_t)i);
             if (w.E < end) uncovered(w.E, end, (uint32_t)i);
@@ -651,25 +690,24 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
             }
             i = j;
         }
-        // dispatch order: stretch by stretch, chunk by chunk, window fastest (a chunk sweeps its rows contiguously);
-        // every chunk is padded to a multiple of 8 workgroups so that window w of every chunk runs on XCD w % 8.
-        // A workgroup costs about the same whatever it holds (profiles/r02_walk.md), so a matrix becomes as few chunks as
-        // the workgroup shape allows, of equal height, each with its own rows-per-wavefront count.
-        // The leftover workgroups (sincos per sample: VALU-bound) are dealt out in groups of 8 between the chunks, evenly
+        // dispatch order: stretch by stretch, span by span, window fastest (a span sweeps its rows contiguously);
+        // every span is padded to a multiple of 8 workgroups so that window w of every span runs on XCD w % 8.
+        // The leftover workgroups (sincos per sample: VALU-bound) are dealt out in groups of 8 between the spans, evenly
         // over the grid, so that their arithmetic runs beside memory-bound matrix workgroups on every CU instead of in a
         // block of its own (all at the front: 5-8 % of the 600-second replay for 1 % of its samples; at the end: worse).
-        const uint32_t waves = walk_shape(tnw).waves, max_upw = walk_shape(tnw).rows_per_wave, span = walk_shape(tnw).span;
+        const WalkShape shape = walk_shape(tnw);
         uint64_t m_groups = 0;
-        for (const WalkSeg &m : mats) m_groups += (uint64_t)((m.nw + 7) / 8) * walk_chunks(m, tnw);
+        for (const WalkSeg &m : mats) m_groups += walk_workgroups(m, tnw) / 8;
         const uint64_t l_groups = (left_wg + 7) / 8;
         uint64_t wg = 0, m_done = 0, l_done = 0;
+        bool plain_spans = true;                            // every span: one window per workgroup, two rows per wavefront
         auto deal_leftovers = [&](uint64_t upto) {          // leftover groups [l_done, upto) go here
             for (; l_done < upto; ++l_done) {
                 WalkSeg g;
                 memset(&g, 0, sizeof g);
                 g.wg_base = (uint32_t)wg;
                 g.row0 = (uint32_t)(l_done * 8);                                        // first leftover block of the group
-                g.nw = (uint32_t)std::min<uint64_t>(8, left_wg - l_done * 8);
+                g.nwg = (uint32_t)std::min<uint64_t>(8, left_wg - l_done * 8);
                 g.upw = 0;                                                                // marks a leftover group
                 wg += 8;
                 plan.walk.push_back(g);
@@ -679,15 +717,18 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
             const uint32_t k = walk_chunks(mats[mi], tnw);
             for (uint32_t c = 0; c < k; ++c) {
                 WalkSeg w = mats[mi];
-                const uint32_t base = w.rows / k, rem = w.rows % k;
-                const uint32_t h = base + (c < rem ? 1u : 0u);
-                w.row0 = c * base + std::min(c, rem);
+                uint32_t h;
+                span_rows(w, k, c, &w.row0, &h);
+                const SpanShape sh = span_shape(h, shape);
                 w.row_end = w.row0 + h;
-                w.upw = span ? 2u : std::max(std::min(2u, max_upw), (h + waves - 1) / waves);
+                w.upw = sh.upw;
+                w.wshift = sh.wshift;
+                w.nwg = (w.nw + (1u << sh.wshift) - 1) >> sh.wshift;
                 w.wg_base = (uint32_t)wg;
-                wg += (w.nw + 7) & ~7u;
+                if (sh.wshift != 0 || sh.upw != 2) plain_spans = false;
+                wg += (w.nwg + 7) & ~7u;
                 plan.walk.push_back(w);
-                m_done += (w.nw + 7) / 8;
+                m_done += (w.nwg + 7) / 8;
                 deal_leftovers(m_groups ? l_groups * m_done / m_groups : 0);
             }
         }
@@ -698,30 +739,28 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         ln.walk.n_walk_wg = (uint32_t)wg;            // the whole grid, leftover groups included
         ln.walk.n_left_wg = (uint32_t)left_wg;       // leftover blocks among them
         ln.walk.n_segs = (uint32_t)ns;
-        ln.walk.waves = walk_shape(tnw).waves;
-        ln.walk.rows_per_wave = walk_shape(tnw).rows_per_wave;
-        ln.walk.compute_slice = 0;
-        ln.walk.span = span;
+        ln.walk.waves = shape.waves;
+        ln.walk.span = shape.span;
         memset(&ln.walk.uni, 0, sizeof ln.walk.uni);
         ln.walk.auto_shape = (!tn.walk_waves && !tn.walk_span) ? 1u : 0u;
-        if (span && mats.size() == 1 && !(tn.walk_flags & 1u)) {      // one matrix: the kernel takes it from its arguments
+        // one matrix: the kernel takes it from its arguments (no such kernel is built for 8 wavefronts: no pair's cut wants them)
+        if (mats.size() == 1 && plain_spans && !(tn.walk_flags & 1u) && shape.waves != 8) {
             const uint32_t k = walk_chunks(mats[0], tnw);
             ln.walk.uni.seg = mats[0];
             ln.walk.uni.seg.upw = 2;
+            ln.walk.uni.seg.nwg = mats[0].nw;
             ln.walk.uni.n_spans = k;
             ln.walk.uni.base = mats[0].rows / k;
             ln.walk.uni.rem = mats[0].rows % k;
             ln.walk.uni.nw8 = (mats[0].nw + 7) & ~7u;
             if ((uint64_t)k + (left_wg + ln.walk.uni.nw8 - 1) / ln.walk.uni.nw8 > 65535u) ln.walk.uni.n_spans = 0;   // grid rows
         }
-        for (const WalkSeg &m : mats) if (m.tab_off == kWalkNoTable) ln.walk.compute_slice = 1;
-        for (const WalkSeg &m : mats) if (span && m.tab_off != kWalkNoTable) plan.error = "span launches evaluate every slice";
         plan.launches.push_back(ln);
         // sentinels end the kernels' forward scans; hints give the scan its starting point
         WalkSeg wend;
         memset(&wend, 0, sizeof wend);
         wend.wg_base = 0xffffffffu;
-        wend.upw = 1;
+        wend.upw = 2;
         plan.walk.push_back(wend);
         plan.left.push_back({0, 0, 0, 0xffffffffu, 0});
         const uint64_t n_wh = (wg >> kWalkHintShift) + 1;
@@ -752,6 +791,8 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         ln.tiles.m1 = hi;
         ln.tiles.tile_lo = lo / tile;
         ln.tiles.n_tiles = (hi + tile - 1) / tile - ln.tiles.tile_lo;
+        ln.tiles.legacy = 0;
+        ln.tiles.pad = 0;
         plan.launches.push_back(ln);
         tile_ranges.push_back({lo, hi});
     };
@@ -805,7 +846,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
     }
 }
 
-void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
+void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes, int in_fmt, int out_fmt)
 {
     const uint32_t ns = (uint32_t)plan.segs.size();
     auto put = [&](uint64_t g, uint32_t n) {
@@ -838,8 +879,11 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
             for (uint64_t g = r.B; g < r.r1; ++g) generic(r.seg_lo, g);
         } else if (ln.kind == 2) {
             const WalkArgs &wa = ln.walk;
+            SpanLaunch sl;
+            if (!span_launch_shape(wa, in_fmt, out_fmt, &sl)) { put(0, 0xfffffff5u); continue; }
+            const uint32_t split = span_split(in_fmt, out_fmt), cols = kWalkWindow / split;
             if (wa.uni.n_spans) {
-                // a one-matrix launch takes the spans from its arguments: they must be the descriptor list's spans
+                // a one-matrix launch takes the spans from its arguments: the plan's must be the descriptor list's spans
                 uint32_t c = 0;
                 for (size_t i = 0; i + 1 < plan.walk.size(); ++i) {
                     const WalkSeg &d = plan.walk[i];
@@ -847,74 +891,90 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes)
                     const WalkUni &u = wa.uni;
                     const uint32_t row0 = c * u.base + std::min(c, u.rem), row_end = row0 + u.base + (c < u.rem ? 1u : 0u);
                     if (d.A != u.seg.A || d.E != u.seg.E || d.L != u.seg.L || d.nw != u.seg.nw || d.period != u.seg.period || d.phase != u.seg.phase ||
-                        memcmp(&d.ratio, &u.seg.ratio, 4) != 0 || d.row0 != row0 || d.row_end != row_end || d.tab_off != kWalkNoTable ||
+                        memcmp(&d.ratio, &u.seg.ratio, 4) != 0 || d.row0 != row0 || d.row_end != row_end || d.wshift != 0 || d.upw != 2 || d.nwg != d.nw ||
                         u.nw8 != ((d.nw + 7u) & ~7u)) put(0, 0xfffffff8u);
                     ++c;
                 }
                 if (c != wa.uni.n_spans) put(0, 0xfffffff7u);
             }
+            // one workgroup of a span (span_body): windows (w << wshift) ... of rows [row0, row_end), `half` of each where
+            // a window is shared by two workgroups
+            auto span_wg = [&](const WalkSeg &ws, uint32_t w, uint32_t half, bool multi) {
+                const uint32_t wshift = multi ? ws.wshift : 0u;
+                // the launch's wavefronts must split evenly over the windows, and hold every row's staging (xpose) slot
+                if (ws.upw != 2 || wshift > kSpanMaxShift || sl.waves % (1u << wshift) != 0 ||
+                    ws.row_end > ws.rows || ws.row_end <= ws.row0) { put(0, 0xfffffffbu); return; }
+                const uint32_t P = ws.period;
+                const uint32_t colbase = ((w * split + half) << wshift) * cols;
+                const uint32_t n_entries = (cols << wshift) + kWalkPad;
+                if ((uint64_t)ws.phase + (uint64_t)colbase + (uint64_t)P * kWalkPad > 0xffffffffull) { put(0, 0xfffffff6u); return; }
+                const uint32_t ub = (ws.phase + colbase + P * kWalkPad - kWalkPad) % P;                 // the kernel's 32-bit arithmetic
+                for (uint32_t sub = 0; sub < (1u << wshift); ++sub) {
+                    const uint32_t col0 = colbase + sub * cols;
+                    for (uint32_t r = ws.row0; r < ws.row_end; ++r) {
+                        const uint64_t ideal = ws.A + (uint64_t)r * ws.L;
+                        const uint64_t row0 = ideal & ~31ull;
+                        const uint32_t delta = (uint32_t)ideal & 31u;
+                        const uint64_t nxt = (ideal + ws.L) & ~31ull;
+                        const uint32_t rowlen = (uint32_t)((nxt < ws.E ? nxt : ws.E) - row0);
+                        for (uint32_t cl = 0; cl < cols; ++cl) {
+                            const uint32_t c = col0 + cl;
+                            if (c >= rowlen) break;                                   // lanes past the row are masked
+                            const uint32_t j = kWalkPad - delta + sub * cols + cl;    // index in the workgroup's slice
+                            if (j >= n_entries) { put(row0 + c, 0xffffffffu); continue; }
+                            uint32_t t = ub + j;
+                            if (P > n_entries) t = t >= P ? t - P : t;
+                            else               t %= P;
+                            if (t >= P) { put(row0 + c, 0xfffffffdu); continue; }
+                            put(row0 + c, t + 1u);
+                        }
+                    }
+                }
+            };
+            auto leftover = [&](uint32_t e) {
+                if (e >= wa.n_left_wg) { put(0, 0xfffffffau); return; }
+                uint32_t li = plan.left_hint[e >> kLeftHintShift];
+                while (plan.left[li + 1].wg_off <= e) ++li;
+                const LeftRange &lr = plan.left[li];
+                const DevSeg &sg = plan.segs[lr.seg];
+                const uint32_t o0 = (e - lr.wg_off) * kLeftBlock;
+                for (uint32_t o = 0; o < kLeftBlock && o0 + o < lr.len; ++o) {
+                    const uint64_t g = lr.start + o0 + o;
+                    put(g, counter_at(sg, g - sg.first));
+                }
+            };
+            if (sl.uni.n_spans) {
+                // the 2-D grid of a one-matrix launch, with the spans as THIS format pair cuts them
+                const WalkUni &u = sl.uni;
+                if ((uint64_t)u.n_spans + sl.left_rows > 65535u) { put(0, 0xfffffff4u); continue; }
+                for (uint32_t c = 0; c < u.n_spans + sl.left_rows; ++c)
+                    for (uint32_t w = 0; w < u.nw8; ++w)
+                        for (uint32_t half = 0; half < split; ++half) {
+                            if (c < u.n_spans) {
+                                if (w >= u.seg.nw) continue;
+                                WalkSeg ws = u.seg;
+                                ws.row0 = c * u.base + std::min(c, u.rem);
+                                ws.row_end = ws.row0 + u.base + (c < u.rem ? 1u : 0u);
+                                span_wg(ws, w, half, false);
+                            } else {
+                                const uint32_t e = (c - u.n_spans) * u.nw8 + w;
+                                if (half != 0 || e >= wa.n_left_wg) continue;
+                                leftover(e);
+                            }
+                        }
+                continue;
+            }
             for (uint32_t b = 0; b < wa.n_walk_wg; ++b) {
                 const WalkSeg &ws = plan.walk[plan.walk_hint[b >> kWalkHintShift]];
-                if (b < ws.wg_base || b - ws.wg_base >= ((ws.nw + 7u) & ~7u)) { put(0, 0xfffffffcu); continue; }   // hint not exact
+                if (b < ws.wg_base || b - ws.wg_base >= ((ws.nwg + 7u) & ~7u)) { put(0, 0xfffffffcu); continue; }   // hint not exact
                 const uint32_t w = b - ws.wg_base;
-                if (w >= ws.nw) continue;
+                if (w >= ws.nwg) continue;
                 if (ws.upw == 0) {                                                 // a group of leftover blocks
-                    const uint32_t e = ws.row0 + w;
-                    if (e >= wa.n_left_wg) { put(0, 0xfffffffau); continue; }
-                    uint32_t li = plan.left_hint[e >> kLeftHintShift];
-                    while (plan.left[li + 1].wg_off <= e) ++li;
-                    const LeftRange &lr = plan.left[li];
-                    const DevSeg &sg = plan.segs[lr.seg];
-                    const uint32_t o0 = (e - lr.wg_off) * kLeftBlock;
-                    for (uint32_t o = 0; o < kLeftBlock && o0 + o < lr.len; ++o) {
-                        const uint64_t g = lr.start + o0 + o;
-                        put(g, counter_at(sg, g - sg.first));
-                    }
+                    leftover(ws.row0 + w);
                     continue;
                 }
-                const TableBuild *tb = nullptr;
-                for (const TableBuild &t : plan.tables) if (t.off == ws.tab_off) tb = &t;
-                if (ws.upw < 1 || ws.upw > wa.rows_per_wave || ws.row_end > ws.rows || ws.row_end <= ws.row0 ||
-                    ws.row_end - ws.row0 > (wa.span ? std::max(wa.span, kSpanWhole) : wa.waves * ws.upw) || (wa.span && ws.tab_off != kWalkNoTable)) { put(0, 0xfffffffbu); continue; }
-                for (uint32_t r = ws.row0; r < ws.row_end; ++r) {
-                    const uint64_t ideal = ws.A + (uint64_t)r * ws.L;
-                    const uint64_t row0 = ideal & ~31ull;
-                    const uint32_t delta = (uint32_t)ideal & 31u;
-                    const uint64_t nxt = (ideal + ws.L) & ~31ull;
-                    const uint32_t rowlen = (uint32_t)((nxt < ws.E ? nxt : ws.E) - row0);
-                    for (uint32_t cl = 0; cl < kWalkWindow; ++cl) {
-                        const uint32_t c = w * kWalkWindow + cl;
-                        if (c >= rowlen) break;                                   // lanes past the row store to the sink
-                        const uint32_t j = kWalkPad - delta + cl;                 // index in the slice
-                        if (j >= kWalkSlice) { put(row0 + c, 0xffffffffu); continue; }
-                        if (ws.tab_off == kWalkNoTable) {                         // the kernel's own counter arithmetic
-                            const uint32_t P = ws.period;
-                            const uint32_t ub = ws.phase + w * kWalkWindow;
-                            uint32_t t;
-                            if (wa.span) {                                        // span kernel: one reduction per workgroup, then one subtraction
-                                if ((uint64_t)ws.phase + (uint64_t)(w + 1) * kWalkWindow + (uint64_t)P * kWalkPad > 0xffffffffull) { put(row0 + c, 0xfffffff6u); continue; }
-                                const uint32_t ub2 = (ws.phase + w * kWalkWindow + P * kWalkPad - kWalkPad) % P;              // the kernel's 32-bit arithmetic
-                                t = ub2 + j;
-                                if (P > kWalkSlice) t = t >= P ? t - P : t;
-                                else                t %= P;
-                                if (t >= P) { put(row0 + c, 0xfffffffdu); continue; }
-                            } else if (ws.L == P) {
-                                t = ub + j + P - kWalkPad;
-                                t = t >= 2u * P ? t - 2u * P : t;
-                                t = t >= P ? t - P : t;
-                                t = t >= P ? t - P : t;
-                                if (t >= P) { put(row0 + c, 0xfffffffdu); continue; }
-                            } else {
-                                t = (uint32_t)(((uint64_t)ub + j + (uint64_t)P * kWalkPad - kWalkPad) % P);
-                            }
-                            put(row0 + c, t + 1u);
-                            continue;
-                        }
-                        const uint32_t x = w * kWalkWindow + j;                   // table index
-                        if (!tb || x >= tb->n_entries) { put(row0 + c, 0xffffffffu); continue; }
-                        put(row0 + c, (uint32_t)(((uint64_t)(tb->n_first - 1u) + x) % tb->period) + 1u);
-                    }
-                }
+                if (ws.nwg != ((ws.nw + (1u << ws.wshift) - 1) >> ws.wshift)) { put(0, 0xfffffff3u); continue; }
+                for (uint32_t half = 0; half < split; ++half) span_wg(ws, w, half, true);
             }
         } else {
             const TileArgs &t = ln.tiles;

@@ -33,7 +33,7 @@ struct TableBuild {     // one corrector table to fill at plan time
 };
 
 struct Launch {
-    int kind;           // 0 = rows kernel, 1 = tile kernel, 2 = walk kernel
+    int kind;           // 0 = rows kernel, 1 = tile kernel, 2 = span kernel
     RowsArgs rows;
     TileArgs tiles;
     WalkArgs walk;
@@ -41,10 +41,10 @@ struct Launch {
 
 // finalize(): which kernels a plan may use
 enum KernelChoice {
-    kChooseAuto = 0,      // rows kernel for up to 8 long stretches, else the walk kernel, else tiles
+    kChooseAuto = 0,      // rows kernel for up to 8 long stretches, else the span kernel, else tiles
     kChooseTileOnly = 1,  // tile kernel only (measurement A/B)
-    kChooseWalk = 2,      // walk kernel wherever a stretch qualifies (measurement A/B)
-    kChooseRows = 3,      // rows kernel or tiles, never the walk kernel (measurement A/B)
+    kChooseWalk = 2,      // span kernel wherever a stretch qualifies (measurement A/B)
+    kChooseRows = 3,      // rows kernel or tiles, never the span kernel (measurement A/B)
 };
 
 // Measurement knobs of finalize() (dpx_set_option; 0 = the planner's own choice everywhere).  None of them changes
@@ -53,25 +53,21 @@ struct PlanTuning {
     uint32_t rows_mult = 0;      // rows kernel: row length = rows_mult * lcm(period, 4)
     uint32_t rows_maxl = 0;      // rows kernel: longest row considered
     uint32_t rows_r = 0;         // rows kernel: rows per wavefront (2, 4 or 8)
-    uint32_t walk_waves = 0;     // walk kernel: wavefronts per workgroup (4, 5, 6 or 8) ...
-    uint32_t walk_rows = 0;      // ... and rows per wavefront (2)
+    uint32_t walk_waves = 0;     // span kernel: wavefronts per workgroup (2, 4, 5 or 8)
     uint32_t rows_compute = 0;   // rows kernel: periods from this many samples on are evaluated in the kernel (0 = the
                                  // planner's default, 0xffffffff = never, 1 = always)
-    uint64_t walk_tilemin = 0;   // walk plans: an uncovered gap at least this long gets its own tile launch
-    int walk_compute = -1;       // walk kernel: 1 = workgroups always evaluate their corrector slices, 0 = always read
-                                 // plan-time tables, -1 = per matrix: tables from walk_table_rows rows on
-    uint32_t walk_table_rows = 0;  // that threshold (0 = the planner's default)
-    uint32_t walk_span = 0;      // span kernel: most rows per span (0 = the planner's default, kSpanRows); 1 = the walk kernel's
-                                 // chunks of waves x rows instead (round 2's shape; also taken whenever a matrix gets a table)
+    uint64_t walk_tilemin = 0;   // span plans: an uncovered gap at least this long gets its own tile launch
+    uint32_t walk_span = 0;      // span kernel: most rows per span (0 = the planner's default: kSpanRows, whole matrices up to
+                                 // kSpanWhole rows, several windows per workgroup for spans of up to 4 rows); >= 2: spans of at
+                                 // most that many rows, one window per workgroup, two rows per wavefront per turn
+    uint32_t walk_flags = 0;     // bit 0: a one-matrix span launch reads descriptors like any other (measurement of what the
+                                 // descriptor load costs); bits 8..: row-length target in KiSamples (measurement)
     bool operator==(const PlanTuning &o) const
     {
         return rows_mult == o.rows_mult && rows_maxl == o.rows_maxl && rows_r == o.rows_r && walk_waves == o.walk_waves &&
-               walk_rows == o.walk_rows && rows_compute == o.rows_compute && walk_tilemin == o.walk_tilemin &&
-               walk_compute == o.walk_compute && walk_table_rows == o.walk_table_rows && walk_span == o.walk_span &&
+               rows_compute == o.rows_compute && walk_tilemin == o.walk_tilemin && walk_span == o.walk_span &&
                walk_flags == o.walk_flags;
     }
-    uint32_t walk_flags = 0;     // bit 0: a one-matrix span launch reads descriptors like any other (measurement of what the
-                                 // descriptor load costs)
 };
 
 struct PlanResult {
@@ -85,7 +81,7 @@ struct PlanResult {
     std::vector<uint32_t> hint;      // stretch index per 2^kHintShift samples
     std::vector<TableBuild> tables;
     std::vector<Launch> launches;
-    // walk-kernel launch (at most one per plan), each list closed by a sentinel
+    // span-kernel launch (at most one per plan), each list closed by a sentinel
     std::vector<WalkSeg> walk;
     std::vector<uint32_t> walk_hint;  // WalkSeg index per 2^kWalkHintShift workgroups
     std::vector<LeftRange> left;
@@ -112,8 +108,9 @@ void finalize(PlanResult &plan, uint32_t tile, int choice /* KernelChoice */, co
 
 // Host mirror of the kernels' index arithmetic (no arithmetic on samples): for every
 // sample of a finalized plan, the counter value the launches would use, and how many
-// times the sample is written.  n_out / writes hold plan.n_samples entries.
-void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes);
+// times the sample is written.  n_out / writes hold plan.n_samples entries.  in_fmt / out_fmt: the format pair of the
+// launch being mirrored (DPX_FMT_*: 0 = i16, 1 = f32) — a span launch cuts its grid per pair (span_launch_shape).
+void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes, int in_fmt = 0, int out_fmt = 0);
 
 // counter value at sample j of a stretch (host mirror of the kernels' counter_at)
 uint32_t counter_at(const DevSeg &s, uint64_t j);

@@ -78,7 +78,7 @@ __device__ __forceinline__ double mad(double a, double b, double c)
 // before adding the half, so it rounds those ties-by-truncation toward +inf: -0x1.921fb6p-1, -0x1.921fb8p-1,
 // -0x1.2d97c8p+1, -0x1.c463acp+2, -0x1.78fdbap+3), where the neighbouring quadrant with the mirrored remainder gives the
 // same two floats.  That is a finite statement and it is checked, not argued: all 2^32 arguments, both libm builds, on
-// the CPU model (tools/sincos_model.c) and on the device (tests/extended/exhaustive_device_sincos.py): 0 mismatches.
+// the CPU model (tests/extended/sincos_model.c) and on the device (tests/extended/exhaustive_device_sincos.py): 0 mismatches.
 constexpr double kTwoOverPi = 0x1.45F306DC9C883p-1;        // 2/pi rounded to double: glibc's hpi_inv / 2^24
 constexpr double kRoundMagic = 0x1.8p52;                   // 1.5 * 2^52: ulp 1, room for |n| < 2^31
 constexpr uint32_t kLargeQuickEnd = 0x4e800000u;           // 2^30: where reduce_large_quick's proof ends (DevSeg::n_huge)
@@ -102,7 +102,7 @@ __device__ __forceinline__ double reduce_small(double x, uint32_t &n_out)
 // r differs from glibc's remainder (a 64-bit fixed-point value truncated below 2^-62 of a quadrant, then rounded to double)
 // in the last place in about one argument of a hundred — and never enough to move either result across a float rounding
 // boundary, nor to pick another quadrant: all 387 973 120 arguments of the range, both signs, both libm builds, give the
-// floats of the integer path (tools/sincos_model.c; without c3 two arguments differ).  Odd symmetry (round-to-nearest
+// floats of the integer path (tests/extended/sincos_model.c; without c3 two arguments differ).  Odd symmetry (round-to-nearest
 // is symmetric) lets the signed x go through: quadrant -n and remainder -r reproduce glibc's "n + sign" bookkeeping,
 // so quad = sidx = n exactly as in the small range.  Checked like the small range: exhaustively, CPU model and device.
 __device__ __forceinline__ double reduce_large_quick(double x, uint32_t &n_out)

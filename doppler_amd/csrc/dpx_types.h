@@ -38,7 +38,7 @@ static_assert(sizeof(DevSeg) == 64, "DevSeg is read with scalar loads");
 
 constexpr uint32_t kSegRows = 2u;        // (most of) this stretch is served by a rows-kernel launch
 constexpr uint32_t kSegTileTable = 4u;   // lut_off / c0 / tmod describe a tile-kernel table
-constexpr uint32_t kSegWalk = 8u;        // (most of) this stretch is a matrix of the walk-kernel launch
+constexpr uint32_t kSegWalk = 8u;        // (most of) this stretch is a matrix of the span-kernel launch
 
 // the first 32 bytes, as exposed through the C ABI (dpx_stretch)
 struct StretchView {
@@ -59,7 +59,7 @@ struct LaunchGeom {
     int block;    // 128 or 256 lanes per workgroup
     int vecs;     // 4-sample groups per lane: 1 or 2
     int autosel = 0;   // the caller set neither: 128 x 2 or 256 x 1 (the same 1024-sample tile) is chosen per launch
-    int legacy_cast = 0;   // dpx_set_i16_cast(DPX_CAST_LEGACY_X86): i16 output wraps instead of saturating (tile-only plans)
+    int legacy_cast = 0;   // dpx_set_i16_cast(DPX_CAST_LEGACY_X86): i16 output wraps instead of saturating (every kernel: a launch-uniform flag)
     uint32_t tile() const { return (uint32_t)block * kSamplesPerLane * (uint32_t)vecs; }
 };
 
@@ -91,36 +91,43 @@ struct RowsArgs {
     uint32_t pad;
 };
 
-// ---- walk kernel: many tabulated periodic stretches in ONE launch (track mode: one stretch per second of stream).
+// ---- span kernel: many periodic stretches in ONE launch (track mode: one stretch per second of stream), and the
+// const-mode stretches whose period does not allow rows of whole 4 KiB pages.
 // A stretch [A, E) is viewed as rows of L samples (L a multiple of the period), row r starting at the 32-sample
 // boundary at or below A + r * L, so every wavefront access is a whole number of 128-byte lines whatever the
-// period.  A workgroup takes one 256-sample column window of ten consecutive rows (5 wavefronts x 2 rows): the
-// window's 288 correctors are fetched once from a plan-time table (or, as a measured alternative, evaluated by the
-// workgroup itself while its sample loads are in flight) and shared through LDS (the tile kernel reads 8 bytes of
-// table per sample, cold, because all tiles of a one-second stretch are in flight at once).  Row r is shifted left by
-// delta_r = (A + r * L) mod 32 samples, so its lanes index the table at kWalkPad - delta_r + column.
-// The launch is a list of row chunks (WalkSeg), stretch by stretch, each chunk padded to a multiple of 8 workgroups.
-struct WalkSeg {           // one span (span kernel: up to 12 rows) or row chunk (walk kernel: waves x rows per wavefront) of one stretch's matrix
+// period.  Row r is shifted left by delta_r = (A + r * L) mod 32 samples, so its lanes use the correctors of the
+// columns delta_r to the right.  A workgroup takes a 256-sample column window of a SPAN of rows: it evaluates the
+// window's 288 correctors once with the bit-exact sincos (while its first rows' loads are in flight), shares them
+// through LDS, and its wavefronts mix and store the rows, `upw` per wavefront per turn.
+// The launch is a list of spans (WalkSeg), stretch by stretch, each padded to a multiple of 8 workgroups.
+//
+// Short matrices (round 4).  A span of up to 4 rows leaves half or three quarters of a 4-wavefront workgroup without rows
+// (the replay's seconds near the closest approach: periods above a quarter of a second), and measures 6-9 points better
+// under 2 wavefronts per window (profiles/r04_walk.md).  A launch has one workgroup size, so such a span's workgroups take
+// 2^wshift ADJACENT windows instead, WAVES >> wshift wavefronts each, one contiguous slice: every wavefront has rows, and
+// the span needs a half or a quarter of the workgroups.  (Three rows per wavefront in one turn for spans of 9-12 rows —
+// instead of a second turn for a part of the wavefronts — was built too and dropped: no gain for those spans, and the
+// second instantiation of the body cost every other span 1.5 points, profiles/r04_walk.md.)
+struct WalkSeg {           // one span of one stretch's matrix, or (upw == 0) a group of up to 8 leftover blocks
     uint64_t A;            // first sample of the matrix (multiple of 32)
     uint64_t E;            // one past its last sample (multiple of 32)
     uint32_t L;            // row length in samples
-    uint32_t tab_off;      // table-pool entry index; entry x = corrector of column x - kWalkPad, 256 nw + kWalkPad entries;
-                           // kWalkNoTable: the workgroups evaluate their slices themselves
-    uint32_t wg_base;      // first workgroup of this chunk (multiple of 8); workgroup wg_base + w takes window w
+    uint32_t wshift;       // log2 of the column windows a workgroup of this span takes (0, 1 or 2)
+    uint32_t wg_base;      // first workgroup of this span (multiple of 8); workgroup wg_base + w takes windows w << wshift ...
     uint32_t nw;           // column windows per row
     uint32_t rows;         // rows of the matrix
-    uint32_t row0;         // first row of this chunk
+    uint32_t row0;         // first row of this span (leftover group: first leftover block)
     uint32_t period;       // of the stretch (L is a multiple of it)
     uint32_t phase;        // counter of sample A, minus 1: column c uses counter ((phase + c) mod period) + 1
     float ratio;           // of the stretch (dsp.rs:121)
-    uint32_t upw;          // rows per wavefront of this chunk (1..kWalkMaxRowsPerWave): wavefront v takes rows row0 + v * upw ...
-    uint32_t row_end;      // ... below row_end, one past the chunk's last row (<= row0 + waves * upw, <= rows)
-    uint32_t pad;
+    uint32_t upw;          // rows per wavefront per turn: 2 (0: a group of leftover blocks)
+    uint32_t row_end;      // one past the span's last row (<= rows)
+    uint32_t nwg;          // workgroups of this span that have work: ceil(nw >> wshift) (leftover group: blocks in the group)
 };
 static_assert(sizeof(WalkSeg) == 64, "WalkSeg is read with scalar loads");
 
-// what the walk kernel's matrices do not cover (heads, tails, lead-ins, untabulated stretches too short for
-// a tile launch): ranges inside ONE stretch each, evaluated sample by sample in 256-sample blocks
+// what the span launch's matrices do not cover (heads, tails, lead-ins, stretches too short for a matrix or a tile
+// launch): ranges inside ONE stretch each, evaluated sample by sample in blocks of kLeftBlock samples
 struct LeftRange {
     uint64_t start;
     uint32_t len;
@@ -130,29 +137,28 @@ struct LeftRange {
 };
 static_assert(sizeof(LeftRange) == 24, "LeftRange is read with scalar loads");
 
-constexpr uint32_t kWalkNoTable = 0xffffffffu;
-constexpr uint32_t kWalkPad = 32;          // table entries before column 0 (the largest row shift is 31)
+constexpr uint32_t kWalkPad = 32;          // slice entries before column 0 (the largest row shift is 31)
 constexpr uint32_t kWalkWindow = 256;      // samples per column window
 constexpr uint32_t kWalkMinL = 8192;       // no row is shorter (a multiple of the period otherwise)
 constexpr uint32_t kWalkRowTarget = 262144; // long matrices: the multiple of the period that reaches this many samples (1 MB of i16) per row
-constexpr int kWalkHintShift = 3;          // one WalkSeg index per 8 workgroups: exact, every chunk is padded to a multiple of 8
+constexpr int kWalkHintShift = 3;          // one WalkSeg index per 8 workgroups: exact, every span is padded to a multiple of 8
 constexpr int kLeftHintShift = 4;          // one LeftRange hint per 16 leftover workgroups
 constexpr uint32_t kLeftBlock = 1024;      // samples per leftover workgroup
-constexpr uint32_t kWalkWaves = 5;         // wavefronts per workgroup (const-mode walks; track-shaped plans: kWalkWavesTrack) ...
-constexpr uint32_t kWalkWavesTrack = 4;
-constexpr uint32_t kWalkRowsPerWave = 2;   // ... and the most rows a wavefront takes by default (measured best; the kernel handles 1..4 per chunk)
-constexpr uint32_t kWalkMaxRowsPerWave = 4;
-constexpr uint32_t kWalkSlice = kWalkWindow + kWalkPad;   // table entries a window needs: 288
-constexpr uint32_t kSpanRows = 8;          // span kernel: most rows of a matrix one workgroup keeps its window for (dpx_options.walk_span): one turn of 4 x 2
-constexpr uint32_t kSpanWhole = 12;        // ... but a matrix of up to this many rows is one span
-constexpr uint32_t kSpanWaves = 4;         // span kernel: wavefronts per workgroup
-constexpr uint32_t kWalkSinkBytes = 512 * 16;             // where lanes without a sample store
+constexpr uint32_t kWalkSlice = kWalkWindow + kWalkPad;   // slice entries a window needs: 288
+constexpr uint32_t kSpanRows = 8;          // most rows of a matrix one workgroup keeps its window for (dpx_options.walk_span): one turn of 4 x 2
+constexpr uint32_t kSpanWhole = 12;        // ... but a matrix of up to this many rows is one span (rows 9-12: a second turn of the first wavefronts)
+constexpr uint32_t kSpanWaves = 4;         // wavefronts per workgroup
+#ifndef DPX_SPAN_MAX_SHIFT
+#define DPX_SPAN_MAX_SHIFT 2
+#endif
+constexpr uint32_t kSpanMaxShift = DPX_SPAN_MAX_SHIFT;   // a workgroup takes at most 4 windows (tools/build_variant.sh: 0 or 1 for A/B builds)
 
-// A walk launch that consists of ONE matrix (const mode: an odd period, or a long one) needs no descriptor table at all:
+// A span launch that consists of ONE matrix (const mode: an odd period, or a long one) needs no descriptor table at all:
 // every span is the same WalkSeg but for its rows, which follow from the span's index.  The span kernel then takes the
 // matrix from its kernel arguments (the first dwords preloaded into scalar registers at wavefront launch) and the span
 // from blockIdx.y, and issues its sample loads without the scalar-load round trip that every workgroup of a
-// many-matrix launch starts with (to HBM: each group of 8 workgroups has its own descriptor line).
+// many-matrix launch starts with (to HBM: each group of 8 workgroups has its own descriptor line).  Such spans take one
+// window per workgroup.
 struct WalkUni {
     WalkSeg seg;           // the matrix; row0 / row_end / wg_base unused
     uint32_t n_spans;      // 0: not a one-matrix launch
@@ -161,21 +167,32 @@ struct WalkUni {
 };
 
 struct WalkArgs {
-    uint32_t n_walk_wg;    // workgroups walking matrices
-    uint32_t n_left_wg;    // workgroups evaluating leftover ranges
+    uint32_t n_walk_wg;    // workgroups of the whole grid (spans and leftover groups)
+    uint32_t n_left_wg;    // leftover blocks among them
     uint32_t n_segs;
-    uint32_t waves, rows_per_wave;   // workgroup geometry the descriptors were laid out for (rows_per_wave: the most a chunk may ask for)
-    uint32_t compute_slice;          // informational: 1 if any chunk evaluates its slices itself (WalkSeg::tab_off == kWalkNoTable)
-    uint32_t span;                   // != 0: span kernel — a descriptor is a span of up to this many rows, its workgroups loop over them
-                                     // two rows per wavefront per turn (every slice evaluated); 0: walk kernel, chunks of waves x rows_per_wave
-    WalkUni uni;                     // span launches of one matrix
-    uint32_t auto_shape;             // the caller named neither walk_waves nor walk_span: a one-matrix launch may cut its spans per format pair
+    uint32_t waves;        // wavefronts per workgroup the descriptors were laid out for (2, 4, 5 or 8)
+    uint32_t span;         // most rows per span the descriptors were cut for
+    WalkUni uni;           // launches of one matrix
+    uint32_t auto_shape;   // the caller named neither walk_waves nor walk_span: the launch may choose per format pair
 };
+
+// What ONE launch makes of a plan's span shape for its format pair (the plan does not know the formats): dpx_planner.cpp,
+// span_launch_shape — used by the launch wrapper and by the planner's host simulation alike.
+struct SpanLaunch {
+    WalkUni uni;           // the one-matrix spans as launched (cut again for pairs with an f32 side)
+    uint32_t waves;        // wavefronts per workgroup as launched
+    uint32_t left_rows;    // one-matrix launches: grid rows that hold the leftover blocks
+};
+bool span_launch_shape(const WalkArgs &w, int in_fmt, int out_fmt, SpanLaunch *out);
+// windows of 256 columns are shared by this many workgroups of a format pair (f32 output without the LDS transposition: 2)
+constexpr uint32_t span_split(int in_fmt, int out_fmt) { return (out_fmt == 1 /* DPX_FMT_F32 */) ? 2u : 1u; }
 
 struct TileArgs {
     uint64_t tile_lo;    // first tile of this launch (global tiling from sample 0)
     uint64_t n_tiles;
     uint64_t m0, m1;     // only samples in [m0, m1) are produced
+    uint32_t legacy;     // dpx_set_i16_cast(DPX_CAST_LEGACY_X86): set by the launch wrapper
+    uint32_t pad;
 };
 
 // launch wrappers implemented in dpx_kernels.hip (all asynchronous on `stream`)
@@ -183,10 +200,10 @@ int launch_tiles(const void *d_in, int in_fmt, void *d_out, int out_fmt, const D
                  uint32_t n_segs, const uint32_t *d_hint, const void *d_lut, const TileArgs &t,
                  bool fma, const LaunchGeom &g, void *stream);
 int launch_rows(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,
-                const void *d_lut, const RowsArgs &r, bool fma, void *stream);
-int launch_walk(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs, const void *d_lut,
+                const void *d_lut, const RowsArgs &r, bool fma, int legacy_cast, void *stream);
+int launch_span(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,
                 const WalkSeg *d_walk_desc /* one per 2^kWalkHintShift workgroups */, const LeftRange *d_left,
-                const uint32_t *d_left_hint, void *d_sink, const WalkArgs &w, bool fma, void *stream);
+                const uint32_t *d_left_hint, const WalkArgs &w, bool fma, int legacy_cast, void *stream);
 int launch_build_lut(void *d_lut_entries, uint32_t period, uint32_t n_first, uint32_t n_entries,
                      float ratio, bool fma, void *stream);
 int launch_copy(const void *d_in, void *d_out, uint64_t n_bytes, void *stream);

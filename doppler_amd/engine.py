@@ -72,8 +72,8 @@ class Context:
         check(self._lib.dpx_set_tuning(self._h, block, vecs, variant))
 
     def set_options(self, **opts):
-        """Kernel-shape knobs (dpx_options: rows_mult, rows_maxl, rows_r, rows_compute, walk_waves, walk_rows, walk_compute,
-        walk_tilemin); no arguments restores the defaults. Applies to plans created afterwards."""
+        """Kernel-shape knobs (include/doppler_hip_debug.h, dpx_options: rows_mult, rows_maxl, rows_r, rows_compute, walk_waves,
+        walk_span, walk_flags, walk_tilemin); no arguments restores the defaults. Applies to plans created afterwards."""
         check(self._lib.dpx_set_options(self._h, _lib.make_options(opts)))
 
     def set_libm_contraction(self, fma=True):
@@ -266,9 +266,10 @@ def plan_describe(segments, samplerate, samplenum=0, variant=0):
     return res, fin.value
 
 
-def plan_simulate(segments, samplerate, samplenum=0, block=0, vecs=0, variant=3, options=None):
+def plan_simulate(segments, samplerate, samplenum=0, block=0, vecs=0, variant=3, options=None, pair=("i16", "i16")):
     """Host-only: per-sample counter values the launch list of a plan selects, and per-sample write
-    counts (must all be 1). Returns (counters uint32[n], writes uint8[n]). Needs no GPU."""
+    counts (must all be 1). Returns (counters uint32[n], writes uint8[n]). Needs no GPU.
+    pair: the format pair of the launch being mirrored (a span launch cuts its grid per pair)."""
     lib = _lib_handle()
     segs = list(segments)
     arr = (_lib.Segment * max(1, len(segs)))()
@@ -280,7 +281,7 @@ def plan_simulate(segments, samplerate, samplenum=0, block=0, vecs=0, variant=3,
     counters = np.zeros(n, dtype=np.uint32)
     writes = np.zeros(n, dtype=np.uint8)
     check(lib.dpx_plan_simulate(arr, len(segs), int(samplerate), int(samplenum), block, vecs, variant,
-                                _lib.make_options(options), counters.ctypes.data, writes.ctypes.data, n))
+                                _lib.make_options(options), _FMT[pair[0]], _FMT[pair[1]], counters.ctypes.data, writes.ctypes.data, n))
     return counters, writes
 
 

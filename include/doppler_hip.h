@@ -18,6 +18,15 @@
  * Data is little-endian interleaved IQ: i16 = 4 bytes/sample, f32 = 8 bytes/sample.
  * A context is bound to one GPU and is not thread-safe; distinct contexts are
  * independent (one context per GPU / per process rank).
+ *
+ * This header is the boundary proper (30 entry points: context, the operators of
+ * doppler::dsp, plans over device buffers, the slab stream).  Two more headers ship
+ * with the library and are NOT needed to bind the path:
+ *   doppler_hip_host.h   host-only arithmetic of the callers either side of it: the
+ *                        counter's closed form, the replay schedule of `doppler track`,
+ *                        the SGP4 stand-in for libgpredict;
+ *   doppler_hip_debug.h  measurement knobs, the planner's self-checks, device-memory
+ *                        helpers for callers without a HIP binding (tests, the CLI).
  */
 #ifndef DOPPLER_HIP_H
 #define DOPPLER_HIP_H
@@ -29,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DPX_ABI_VERSION 3
+#define DPX_ABI_VERSION 4
 
 /* reference src/usage.rs:39-42  enum DataType { F32, I16 } */
 #define DPX_FMT_I16 0
@@ -126,101 +135,6 @@ int dpx_ccexpf(dpx_ctx *ctx, dpx_complex32 *z, size_t n);
  * z[k] <- cexpf(0 + i*z[k].im); z[k].re is ignored. */
 int dpx_ccexpf_imag(dpx_ctx *ctx, dpx_complex32 *z, size_t n);
 
-/* Kernel-shape knobs for measurements (all 0 / -1 = the planner's own choice).  They never change a result,
- * only which launch shape produces it; profiles/ names the values behind every alternative it reports. */
-typedef struct dpx_options {
-    uint32_t rows_mult;      /* rows kernel: row length = rows_mult * lcm(period, 4) samples */
-    uint32_t rows_maxl;      /* rows kernel: longest row considered */
-    uint32_t rows_r;         /* rows kernel: rows per wavefront (2, 4 or 8) */
-    uint32_t walk_waves;     /* walk kernel: wavefronts per workgroup (2, 3, 4, 5, 6 or 8); span kernel: 2, 4, 5 or 8 */
-    uint32_t walk_rows;      /* walk kernel: most rows per wavefront a chunk may use (1..4) */
-    int32_t walk_compute;    /* walk kernel: 1 = workgroups always evaluate their corrector slices, 0 = always plan-time tables,
-                              * -1 = per matrix (tables for matrices of at least walk_table_rows rows) */
-    uint32_t walk_table_rows; /* that threshold */
-    uint32_t rows_compute;   /* rows kernel: for periods of at least this many samples an i16 -> i16 launch leaves the table alone,
-                              * its wavefronts evaluate their columns' correctors (0 = the planner's threshold, 0xffffffff = never,
-                              * 1 = always and for every format pair) */
-    uint64_t walk_tilemin;   /* walk plans: uncovered gaps at least this long (samples) get a tile-kernel launch */
-    uint32_t walk_span;      /* span kernel (ABI 3): most rows of a matrix one workgroup keeps its column window for (0 = the planner's
-                              * default, 32); 1 = round 2's walk kernel instead (chunks of walk_waves x walk_rows rows) */
-    uint32_t walk_flags;     /* bit 0: a span launch of ONE matrix reads its descriptors from memory like a many-matrix launch instead
-                              * of taking the matrix from its kernel arguments */
-} dpx_options;
-/* applies to plans created afterwards; NULL restores the defaults */
-int dpx_set_options(dpx_ctx *ctx, const dpx_options *opt);
-
-/* ------------------------------------------------- host-side counter algebra
- * Closed form of the counter rule dsp.rs:125-130 (pure host integer/f32 code). */
-
-/* first n >= n_start with fract(fl32(ratio*fl32(n))) == 0, scanning at most
- * max_scan candidates; *found = 0 if none in range. ratio = shift_hz/(f32)samplerate. */
-int dpx_find_reset(float shift_hz, uint32_t samplerate, uint32_t n_start, uint64_t max_scan,
-                   uint32_t *n_reset, int *found);
-/* value of the counter after `k` samples starting from samplenum0 (constant shift) */
-int dpx_samplenum_after(float shift_hz, uint32_t samplerate, uint32_t samplenum0, uint64_t k,
-                        uint32_t *samplenum);
-
-/* One stretch of the stream in which the counter is a closed form of the
- * sample index j (relative to `first`):  period == 0: n = n_start + j;
- * period > 0: n = ((n_start - 1 + j) mod period) + 1.  lut_len > 0: one period of
- * correctors is tabulated in device memory at plan time for this stretch
- * (lut_len == 0: the kernels evaluate sincos themselves). */
-typedef struct {
-    uint64_t first, count;
-    float ratio;
-    uint32_t n_start, period, lut_len;
-} dpx_stretch;
-
-/* Host-only (no device needed): the stretch list the planner derives for a
- * segment list; writes at most `cap` entries, *n_out = total number. */
-int dpx_plan_describe(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
-                      uint32_t samplenum0, int variant, dpx_stretch *out, size_t cap,
-                      size_t *n_out, uint32_t *final_samplenum);
-
-/* Host-only self-check of a plan's launch list (no device needed): for every sample,
- * the counter value the kernels' index arithmetic selects (counters[n_samples]) and
- * how many launches write it (writes[n_samples], must be exactly 1 everywhere).
- * block / vecs / variant as in dpx_set_tuning (0 = defaults). */
-int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
-                      uint32_t samplenum0, int block, int vecs, int variant, const struct dpx_options *opt,
-                      uint32_t *counters, uint8_t *writes, uint64_t n_samples);
-
-/* Host-only: how the planner lays a segment list out over the kernels (what dpx_run_device will launch). */
-typedef struct dpx_layout {
-    uint64_t n_samples;
-    uint64_t rows_samples;      /* produced by rows-kernel matrices */
-    uint64_t walk_samples;      /* produced by walk-kernel matrices */
-    uint64_t tile_samples;      /* inside tile-kernel launches */
-    uint64_t single_samples;    /* evaluated one by one (ragged edges of rows launches, leftover ranges) */
-    uint64_t table_entries;     /* (cos, sin) pairs tabulated at plan time */
-    uint32_t n_stretches;
-    uint32_t rows_launches, tile_launches, walk_launches;
-    uint32_t walk_matrices, walk_workgroups, leftover_ranges, leftover_workgroups;
-} dpx_layout;
-int dpx_plan_layout(const dpx_segment *segs, size_t n_segs, uint32_t samplerate, uint32_t samplenum0,
-                    int block, int vecs, int variant, const struct dpx_options *opt, dpx_layout *out);
-
-/* ------------------------------------------------ track mode, host side (N2)
- * Host-only.  The per-block shift schedule of `doppler track --time` (reference
- * src/main.rs:156-184: one-block lag, whole seconds truncated through f32, f32 offset add) for a
- * stream of in_bytes, with the range rate supplied per whole second (entry t = range rate at
- * start_time + t s; the last entry is held).  Writes one shift per loop iteration of the reference
- * (floor(in_bytes / 8192) + 1, the last one belonging to the short or empty final block). */
-int dpx_track_schedule(const double *range_rate_km_s, size_t n_table, uint32_t samplerate,
-                       uint32_t frequency_hz, int32_t offset_hz, int has_offset, int in_fmt,
-                       uint64_t in_bytes, float *shift_hz, size_t cap, size_t *n_blocks);
-
-/* Host-only.  NORAD SGP4 (near-earth) + geodetic observer: what the reference reads from
- * predict.sat after predict.update(time) (src/main.rs:162-173).  out[4] = azimuth deg,
- * elevation deg, range km, range rate km/s.  libgpredict is not part of the reference tree:
- * ORBIT PARITY UNPINNED. */
-int dpx_orbit_observe(const char *tle_line1, const char *tle_line2, double lat_deg, double lon_deg,
-                      double alt_m, double unix_time_s, double out[4]);
-
-/* Host-only.  SGP4 state vector `tsince_min` minutes after the element-set epoch:
- * out[6] = x, y, z (km), xdot, ydot, zdot (km/s), true-equator mean-equinox frame. */
-int dpx_orbit_propagate(const char *tle_line1, const char *tle_line2, double tsince_min, double out[6]);
-
 /* ----------------------------------------------- bulk API (device pointers) */
 
 /* constant shift over n_samples starting with counter samplenum0 */
@@ -230,7 +144,6 @@ int dpx_plan_const(dpx_ctx *ctx, float shift_hz, uint32_t samplerate, uint32_t s
  * exactly as the reference carries `samplenr` (main.rs:60) across blocks */
 int dpx_plan_segments(dpx_ctx *ctx, const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
                       uint32_t samplenum0, dpx_plan **plan);
-int dpx_plan_n_samples(const dpx_plan *plan, uint64_t *n_samples);
 int dpx_plan_final_samplenum(const dpx_plan *plan, uint32_t *samplenum);
 void dpx_plan_destroy(dpx_plan *plan);
 
@@ -271,37 +184,10 @@ int dpx_stream_create_multi(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out
                             uint32_t samplenum0, size_t slab_bytes, int slabs_per_ctx, dpx_stream **stream);
 int dpx_stream_acquire(dpx_stream *s, void **pinned_in, size_t *capacity_bytes);
 int dpx_stream_submit(dpx_stream *s, size_t in_bytes, const dpx_segment *segs, size_t n_segs);
-int dpx_stream_pending(const dpx_stream *s, int *n_in_flight);
 int dpx_stream_next(dpx_stream *s, const void **pinned_out, size_t *out_bytes);
 int dpx_stream_release(dpx_stream *s);
 int dpx_stream_samplenum(const dpx_stream *s, uint32_t *samplenum);   /* counter after everything submitted */
-/* Host time dpx_stream_submit has spent so far, by part (microseconds, summed over `slabs` calls): planning (stretch list +
- * launch layout; skipped when the slab buffer's resident plan was made from the same segments at the same counter:
- * `plans_reused`), building and uploading the plan's device image, and enqueueing the two copies, the launch and the event. */
-typedef struct dpx_stream_stats {
-    uint64_t slabs, plans_reused;
-    double plan_us, upload_us, enqueue_us, total_us;
-} dpx_stream_stats;
-int dpx_stream_get_stats(const dpx_stream *s, dpx_stream_stats *out);
 void dpx_stream_destroy(dpx_stream *s);
-
-/* Same access pattern, no arithmetic: 16-byte non-temporal copy of n_bytes.
- * Calibration only (profiles/: what the memory system gives a pure stream). */
-int dpx_debug_copy(dpx_ctx *ctx, const void *d_in, void *d_out, size_t n_bytes, void *hip_stream);
-
-/* Measurement knobs (0 keeps the current value); they apply to plans created afterwards.
- * block / vecs: tile-kernel geometry, lanes per workgroup (128 or 256) and 4-sample groups
- *          per lane (1 or 2); the rows kernel always runs one wavefront x 2, 4 or 8 rows.  Until a call names one,
- *          every launch picks 256 x 1 or 128 x 2 (the same 1024-sample tile) from its output format and
- *          whether the plan has tile tables (measured: DESIGN.md section 4); block = vecs = -1 returns to that.
- * variant: 3 = auto: correctors tabulated wherever a period repeats at least twice; rows kernel for up to
- *              eight long stretches (const mode), walk kernel for more (track mode), tile kernel for the rest;
- *          1 = sincos per sample wherever the period allows it (>= 4);
- *          2 = tabulate whenever the period fits;
- *          4 = auto, but keep everything on the tile kernel;
- *          5 = auto, but use the walk kernel wherever a stretch qualifies;
- *          6 = auto, but never the walk kernel. */
-int dpx_set_tuning(dpx_ctx *ctx, int block, int vecs, int variant);
 
 /* Which build of glibc's sincosf the correctors reproduce bit-for-bit:
  * fma = 1 (default): the FMA build libm selects on every x86-64 CPU with FMA+AVX2;
@@ -321,14 +207,6 @@ int dpx_set_libm_contraction(dpx_ctx *ctx, int fma);
 #define DPX_CAST_SATURATE 0
 #define DPX_CAST_LEGACY_X86 1
 int dpx_set_i16_cast(dpx_ctx *ctx, int mode);
-
-/* --------------------------------------------- device memory helpers
- * For callers without their own HIP runtime binding (ctypes tests, the CLI). */
-int dpx_malloc(dpx_ctx *ctx, size_t bytes, void **d_ptr);
-int dpx_free(dpx_ctx *ctx, void *d_ptr);
-int dpx_memcpy_h2d(dpx_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
-int dpx_memcpy_d2h(dpx_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
-int dpx_synchronize(dpx_ctx *ctx);
 
 #ifdef __cplusplus
 }

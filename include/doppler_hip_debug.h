@@ -1,0 +1,126 @@
+/*
+ * doppler_hip_debug.h — measurement knobs, planner self-checks and helpers of libdoppler_hip.so.
+ *
+ * Nothing here is needed to bind or to use the hot path (doppler_hip.h); none of it changes a result.  What it is for:
+ *   dpx_options / dpx_set_options / dpx_set_tuning   kernel-shape alternatives timed against each other (tools/ab.py,
+ *                                                    profiles/): which launch shape produces the same bytes;
+ *   dpx_plan_describe / _layout / _simulate          the planner's stretch list, launch layout and a host mirror of the
+ *                                                    kernels' index arithmetic (tests/test_host_logic.py, no device needed);
+ *   dpx_debug_copy                                   the memory system's own copy rate (calibration of profiles/);
+ *   dpx_stream_get_stats / _pending, dpx_plan_n_samples   introspection;
+ *   dpx_malloc ... dpx_synchronize                   device memory for callers without a HIP binding (ctypes tests, the CLI).
+ */
+#ifndef DOPPLER_HIP_DEBUG_H
+#define DOPPLER_HIP_DEBUG_H
+
+#include "doppler_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Kernel-shape knobs for measurements (all 0 = the planner's own choice).  They never change a result,
+ * only which launch shape produces it; profiles/ names the values behind every alternative it reports. */
+typedef struct dpx_options {
+    uint32_t rows_mult;      /* rows kernel: row length = rows_mult * lcm(period, 4) samples */
+    uint32_t rows_maxl;      /* rows kernel: longest row considered */
+    uint32_t rows_r;         /* rows kernel: rows per wavefront (2, 4 or 8) */
+    uint32_t rows_compute;   /* rows kernel: for periods of at least this many samples an i16 -> i16 launch leaves the table alone,
+                              * its wavefronts evaluate their columns' correctors (0 = the planner's threshold, 0xffffffff = never,
+                              * 1 = always and for every format pair) */
+    uint32_t walk_waves;     /* span kernel: wavefronts per workgroup (2, 4, 5 or 8) */
+    uint32_t walk_span;      /* span kernel: most rows of a matrix one workgroup keeps its column window for.  0 = the planner's
+                              * own cut: spans of 8, a matrix of up to 12 rows whole, several adjacent windows per workgroup for
+                              * spans of up to 4 rows; >= 2: spans of at most
+                              * that many rows, one window per workgroup, two rows per wavefront per turn */
+    uint32_t walk_flags;     /* bit 0: a span launch of ONE matrix reads its descriptors from memory like a many-matrix launch instead
+                              * of taking the matrix from its kernel arguments; bits 8..: row-length target in KiSamples */
+    uint32_t reserved;
+    uint64_t walk_tilemin;   /* span plans: uncovered gaps at least this long (samples) get a tile-kernel launch */
+} dpx_options;
+/* applies to plans created afterwards; NULL restores the defaults */
+int dpx_set_options(dpx_ctx *ctx, const dpx_options *opt);
+
+/* One stretch of the stream in which the counter is a closed form of the
+ * sample index j (relative to `first`):  period == 0: n = n_start + j;
+ * period > 0: n = ((n_start - 1 + j) mod period) + 1.  lut_len > 0: one period of
+ * correctors is tabulated in device memory at plan time for this stretch
+ * (lut_len == 0: the kernels evaluate sincos themselves). */
+typedef struct {
+    uint64_t first, count;
+    float ratio;
+    uint32_t n_start, period, lut_len;
+} dpx_stretch;
+
+/* Host-only (no device needed): the stretch list the planner derives for a
+ * segment list; writes at most `cap` entries, *n_out = total number. */
+int dpx_plan_describe(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
+                      uint32_t samplenum0, int variant, dpx_stretch *out, size_t cap,
+                      size_t *n_out, uint32_t *final_samplenum);
+
+/* Host-only self-check of a plan's launch list (no device needed): for every sample,
+ * the counter value the kernels' index arithmetic selects (counters[n_samples]) and
+ * how many launches write it (writes[n_samples], must be exactly 1 everywhere).
+ * block / vecs / variant as in dpx_set_tuning (0 = defaults); in_fmt / out_fmt: the format pair of the launch being
+ * mirrored (a span launch cuts its grid per pair). */
+int dpx_plan_simulate(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
+                      uint32_t samplenum0, int block, int vecs, int variant, const struct dpx_options *opt,
+                      int in_fmt, int out_fmt, uint32_t *counters, uint8_t *writes, uint64_t n_samples);
+
+/* Host-only: how the planner lays a segment list out over the kernels (what dpx_run_device will launch). */
+typedef struct dpx_layout {
+    uint64_t n_samples;
+    uint64_t rows_samples;      /* produced by rows-kernel matrices */
+    uint64_t walk_samples;      /* produced by span-kernel matrices */
+    uint64_t tile_samples;      /* inside tile-kernel launches */
+    uint64_t single_samples;    /* evaluated one by one (ragged edges of rows launches, leftover ranges) */
+    uint64_t table_entries;     /* (cos, sin) pairs tabulated at plan time */
+    uint32_t n_stretches;
+    uint32_t rows_launches, tile_launches, walk_launches;
+    uint32_t walk_matrices, walk_workgroups, leftover_ranges, leftover_workgroups;
+} dpx_layout;
+int dpx_plan_layout(const dpx_segment *segs, size_t n_segs, uint32_t samplerate, uint32_t samplenum0,
+                    int block, int vecs, int variant, const struct dpx_options *opt, dpx_layout *out);
+
+int dpx_plan_n_samples(const dpx_plan *plan, uint64_t *n_samples);
+
+int dpx_stream_pending(const dpx_stream *s, int *n_in_flight);
+/* Host time dpx_stream_submit has spent so far, by part (microseconds, summed over `slabs` calls): planning (stretch list +
+ * launch layout; skipped when the slab buffer's resident plan was made from the same segments at the same counter:
+ * `plans_reused`), building and uploading the plan's device image, and enqueueing the two copies, the launch and the event. */
+typedef struct dpx_stream_stats {
+    uint64_t slabs, plans_reused;
+    double plan_us, upload_us, enqueue_us, total_us;
+} dpx_stream_stats;
+int dpx_stream_get_stats(const dpx_stream *s, dpx_stream_stats *out);
+
+/* Same access pattern, no arithmetic: 16-byte non-temporal copy of n_bytes.
+ * Calibration only (profiles/: what the memory system gives a pure stream). */
+int dpx_debug_copy(dpx_ctx *ctx, const void *d_in, void *d_out, size_t n_bytes, void *hip_stream);
+
+/* Measurement knobs (0 keeps the current value); they apply to plans created afterwards.
+ * block / vecs: tile-kernel geometry, lanes per workgroup and 4-sample groups per lane: 256 x 1 or 128 x 2 (the same
+ *          1024-sample tile; the two shapes that are built).  Until a call names one, every launch picks between them
+ *          from its output format and whether the plan has tile tables (measured: DESIGN.md section 4);
+ *          block = vecs = -1 returns to that.
+ * variant: 3 = auto: rows kernel (one period of correctors tabulated) for up to eight long stretches (const mode),
+ *              span kernel for more (track mode) and for odd periods, tile kernel for the rest;
+ *          1 = sincos per sample wherever the period allows it (>= 4);
+ *          2 = tabulate whenever the period fits;
+ *          4 = auto, but keep everything on the tile kernel;
+ *          5 = auto, but use the span kernel wherever a stretch qualifies;
+ *          6 = auto, but never the span kernel. */
+int dpx_set_tuning(dpx_ctx *ctx, int block, int vecs, int variant);
+
+/* --------------------------------------------- device memory helpers
+ * For callers without their own HIP runtime binding (ctypes tests, the CLI). */
+int dpx_malloc(dpx_ctx *ctx, size_t bytes, void **d_ptr);
+int dpx_free(dpx_ctx *ctx, void *d_ptr);
+int dpx_memcpy_h2d(dpx_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int dpx_memcpy_d2h(dpx_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int dpx_synchronize(dpx_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,3 +1,19 @@
+/*
+ * TEST INFRASTRUCTURE — CPU model of the device's two argument reductions (doppler_amd/csrc/dpx_sincos.h,
+ * reduce_small / reduce_large_quick, round 4), enumerated against the oracle's restated glibc 2.35 sincosf
+ * (oracle/sincosf_glibc.c, itself pinned to libm over all 2^32 arguments).
+ *
+ * The device code replaces glibc's operation sequence in two places by a cheaper one that is claimed to give the
+ * same two floats for every argument of its range.  That claim is a finite statement; this program checks it
+ * argument by argument with the same IEEE double operations the device executes (fma, add, mul, conversion):
+ *     sincos_model [--v 0|1] [--plain] [--lo BITS] [--hi BITS]
+ *       default: the large range, |y| in [120, 2^30), both signs: quick three-term reduction vs the integer path
+ *       --plain: |y| in [2^-12, 120): rounding by fused multiply-add against 1.5*2^52 vs glibc's truncating conversion
+ *       --v:     libm build (1 = FMA contraction, 0 = SSE2)
+ * Exit status 0 iff there is no mismatch.  tests/test_oracle.py runs all four enumerations (about 20 s on 8 cores);
+ * the device itself is enumerated by tests/extended/exhaustive_device_sincos.py (profiles/r04_exhaustive_device_sincos.json).
+ * Build: gcc -O2 -mfma -ffp-contract=off -Ioracle -o sincos_model tests/extended/sincos_model.c oracle/sincosf_glibc.c -lm -lpthread
+ */
 #define _GNU_SOURCE
 #include <math.h>
 #include <pthread.h>
@@ -50,4 +66,4 @@ int main(int argc,char**argv){ uint32_t lo=0x42f00000u,hi=0x4e800000u; int v=1,n
   uint64_t n=0,m=0; double mx=0,mn=10;
   for(int t=0;t<nt;++t){ pthread_join(th[t],0); n+=jb[t].n; m+=jb[t].mism; if(jb[t].max_ok_xr>mx)mx=jb[t].max_ok_xr; if(jb[t].min_bad_xr<mn)mn=jb[t].min_bad_xr; for(uint64_t k=0;k<jb[t].mism&&k<16;++k) printf("  bad %08x\n",jb[t].bads[k]); }
   printf("mode=%s v=%d range %08x..%08x n=%llu mismatches=%llu  max|xr| among ok=%.17g (pi/4=%.17g) min|xr| among bad=%.17g\n",mode?"plain":"large",v,lo,hi,(unsigned long long)n,(unsigned long long)m,mx,M_PI/4,mn);
-  return 0; }
+  return m!=0; }

@@ -69,7 +69,7 @@ def same_in_slabs(got, want, what):
 def test_config3_8gib_const_stream_in_eight_rank_chunks(ctx, orc, shift):
     """configs[3]: `doppler const -i i16` on 8 GiB (2 147 483 648 samples) of synthetic IQ, time-chunk sharded over 8
     ranks = 8 x 1 GiB.  5000 Hz is the headline ratio (period 1024: every chunk starts on a period boundary); 5001 Hz
-    has the odd period 113 027, so the seeds at r * 2^28 land mid-period and the chunks run on the walk kernel."""
+    has the odd period 113 027, so the seeds at r * 2^28 land mid-period and the chunks run on the span kernel."""
     from doppler_amd import shard
     world, n, rate = 8, 1 << 31, 1024000
     bufs = DeviceBuffers(ctx, (n // world) * 4, (n // world) * 4)

@@ -266,7 +266,7 @@ def test_const_stream_bulk_vs_oracle(ctx, orc, intype, outtype):
     want, sn_w = orc.const_stream(x, intype, outtype, 5000, 1024000, threads=8)
     sn_w = orc.advance_samplenum(0, 5000.0, 1024000, n)
     try:
-        for variant, block, vecs in [(3, 256, 1), (4, 256, 1), (1, 256, 1), (2, 128, 1), (4, 128, 2), (1, 256, 2)]:
+        for variant, block, vecs in [(3, 256, 1), (4, 256, 1), (1, 256, 1), (2, 128, 2), (4, 128, 2), (1, 128, 2)]:
             ctx.set_tuning(block, vecs, variant)
             got, fin = run_bulk(ctx, x, intype, outtype, [(n, 5000.0)], 1024000)
             assert fin == sn_w
@@ -349,8 +349,8 @@ def oracle_segments(orc, x, intype, outtype, segs, rate, sn0=0):
 
 
 @pytest.mark.parametrize("intype,outtype", [("i16", "i16"), ("f32", "f32"), ("i16", "f32"), ("f32", "i16")])
-def test_walk_kernel_plans_vs_oracle(ctx, orc, intype, outtype):
-    """Track-shaped plans with more than eight tabulated stretches run as ONE walk-kernel launch (matrices with
+def test_span_kernel_plans_vs_oracle(ctx, orc, intype, outtype):
+    """Track-shaped plans with more than eight periodic stretches run as ONE span-kernel launch (matrices with
     shifted, line-aligned rows; leftover blocks for heads, tails and lead-ins) plus tile launches for long
     untabulated gaps — byte for byte against the oracle, odd periods, short periods, carried counters."""
     import doppler_amd
@@ -369,7 +369,7 @@ def test_walk_kernel_plans_vs_oracle(ctx, orc, intype, outtype):
         got, fin = run_bulk(ctx, x, intype, outtype, segs, rate, sn0=sn0)
         assert fin == sn
         assert_same_bytes(got, want, outtype, "walk plan %d %s->%s" % (i, intype, outtype))
-    # the same arithmetic when a single long stretch is forced onto the walk kernel (row chunks of 32 rows)
+    # the same arithmetic when a single long stretch is forced onto the span kernel (a one-matrix launch)
     segs, rate = [(3000000 + 77, 5001.0)], 1024000
     x = make_iq(intype, segs[0][0], 950)
     want, sn = oracle_segments(orc, x, intype, outtype, segs, rate)
@@ -381,36 +381,6 @@ def test_walk_kernel_plans_vs_oracle(ctx, orc, intype, outtype):
         ctx.set_tuning(0, 0, 3)
     assert fin == sn
     assert_same_bytes(got, want, outtype, "forced walk %s->%s" % (intype, outtype))
-
-
-@pytest.mark.parametrize("compute", [0, 1])
-@pytest.mark.parametrize("waves,max_rows", [(4, 4), (5, 4), (6, 4), (8, 4), (5, 1), (5, 2), (5, 3), (8, 2), (2, 2), (3, 2), (4, 2)])
-def test_walk_kernel_workgroup_shapes_and_on_the_fly_slices(ctx, orc, waves, max_rows, compute):
-    """Every workgroup shape of the walk kernel, with plan-time tables (compute=0) and with the workgroups evaluating
-    their corrector slices themselves (compute=1), with chunks of 1..4 rows per wavefront, on matrices whose row counts
-    leave 1..waves-1 wavefronts of a chunk without rows (those wavefronts end before the workgroup's barrier), all
-    format pairs."""
-    import doppler_amd
-    rate = 256000
-    # periods 8192..40000 at this rate: rows = count / period takes many residues modulo 2 * waves
-    segs = [(rate + 2048 * k, float(np.float32(-3000.0 + 517.3 * k))) for k in range(9)] + [(5 * rate // 2, 1000.0), (3 * rate, 7.0)]
-    n = sum(c for c, _ in segs)
-    opts = dict(walk_waves=waves, walk_rows=max_rows, walk_compute=compute, walk_span=1)     # walk_span=1: the walk kernel, not spans
-    lay = doppler_amd.plan_layout(segs, rate, variant=5, options=opts)
-    assert lay["walk_launches"] == 1 and lay["walk_matrices"] >= 9 and lay["rows_launches"] == 0, lay
-    assert lay["table_entries"] == 0 or not compute
-    ctx.set_tuning(0, 0, 5)
-    ctx.set_options(**opts)
-    try:
-        for intype, outtype in (("i16", "i16"), ("f32", "i16"), ("i16", "f32"), ("f32", "f32")):
-            x = make_iq(intype, n, 1300 + waves, full_scale=True)
-            want, sn = orc.segments_stream(x, intype, outtype, segs, rate, threads=16)
-            got, fin = run_bulk(ctx, x, intype, outtype, segs, rate)
-            assert fin == sn
-            assert_same_bytes(got, want, outtype, "walk %d waves x <=%d rows, compute=%d, %s->%s" % (waves, max_rows, compute, intype, outtype))
-    finally:
-        ctx.set_options()
-        ctx.set_tuning(0, 0, 3)
 
 
 @pytest.mark.parametrize("waves", [2, 4, 5, 8])
@@ -439,6 +409,35 @@ def test_span_kernel_shapes(ctx, orc, waves, span):
     finally:
         ctx.set_options()
         ctx.set_tuning(0, 0, 3)
+
+
+@pytest.mark.parametrize("waves", [0, 2, 5, 8])
+def test_span_kernel_short_and_medium_matrices(ctx, orc, waves):
+    """Round 4: spans of up to 4 rows give their workgroups 2 (up to 2 rows: 4) adjacent windows, WAVES / 2 (/ 4) wavefronts
+    each and one contiguous slice; whole matrices of 9-12 rows give their first wavefronts a second turn.  Matrices of 2..13
+    rows of one period (8192 samples at 262 144 Hz, and an odd period at 256 000 Hz: every row shifted differently against
+    the slice), ragged last rows, heads, tails and lead-ins between them; the planner's own shape (waves = 0: 4 wavefronts,
+    8 at launch for f32 -> i16) and the others a caller may name; all format pairs, byte for byte."""
+    import doppler_amd
+    plans = [
+        ([((2 + (5 * k) % 12) * 8192 + 1000 * (k % 3), 32.0 * (2 * k + 1)) for k in range(12)], 262144),
+        ([(int(2.2 * 256000 / (1 + k % 7)) + 2048 * k, float(np.float32(-3000.0 + 517.3 * k))) for k in range(16)], 256000),
+    ]
+    opts = dict(walk_waves=waves) if waves else {}
+    ctx.set_options(**opts)
+    try:
+        for pi, (segs, rate) in enumerate(plans):
+            lay = doppler_amd.plan_layout(segs, rate, options=opts)
+            assert lay["walk_launches"] == 1 and lay["walk_matrices"] >= 6 and lay["rows_launches"] == 0, lay   # (a lead-in may leave a stretch under two rows)
+            n = sum(c for c, _ in segs)
+            for intype, outtype in (("i16", "i16"), ("f32", "i16"), ("i16", "f32"), ("f32", "f32")):
+                x = make_iq(intype, n, 2300 + waves + pi, full_scale=True)
+                want, sn = orc.segments_stream(x, intype, outtype, segs, rate, threads=16)
+                got, fin = run_bulk(ctx, x, intype, outtype, segs, rate)
+                assert fin == sn
+                assert_same_bytes(got, want, outtype, "short/medium matrices, plan %d, %d waves, %s->%s" % (pi, waves, intype, outtype))
+    finally:
+        ctx.set_options()
 
 
 @pytest.mark.parametrize("span,flags", [(0, 0), (0, 1), (3, 0), (40, 0), (4096, 0)])
@@ -500,22 +499,10 @@ def test_rows_kernel_evaluates_its_correctors(ctx, orc, rows_compute, rows_r):
         ctx.set_tuning(0, 0, 3)
 
 
-def test_walk_kernel_plans_with_on_the_fly_slices(ctx, orc):
-    """The plan shapes of test_walk_kernel_plans_vs_oracle and test_walk_kernel_random_plans again with walk_compute=1
-    (no corrector tables at all)."""
-    ctx.set_options(walk_compute=1)
-    try:
-        for pair in (("i16", "i16"), ("f32", "i16")):
-            test_walk_kernel_plans_vs_oracle(ctx, orc, *pair)
-        test_walk_kernel_random_plans(ctx, orc)
-    finally:
-        ctx.set_options()
-
-
-def test_walk_kernel_random_plans(ctx, orc):
+def test_span_kernel_random_plans(ctx, orc):
     """Seeded random track-shaped plans: 9-30 segments of 0.05-1.3 s with arbitrary f32 shifts, random rate,
     format pair and counter start — whatever mixture of walk matrices, leftover ranges and tile launches the
-    planner picks (auto, or forced onto the walk kernel) must reproduce the oracle byte for byte."""
+    planner picks (auto, or forced onto the span kernel) must reproduce the oracle byte for byte."""
     import doppler_amd
     rng = np.random.default_rng(4242)
     used_walk = 0
@@ -542,19 +529,19 @@ def test_walk_kernel_random_plans(ctx, orc):
             ctx.set_tuning(0, 0, 3)
         assert fin == sn, (case, segs[:3])
         assert_same_bytes(got, want, outtype, "random walk plan %d (%d segments, %s->%s)" % (case, len(segs), intype, outtype))
-    assert used_walk >= 5      # many of these plans really run on the walk kernel
+    assert used_walk >= 5      # many of these plans really run on the span kernel
 
 
 def test_kernels_stay_inside_the_output_buffer(ctx, orc):
-    """Guard bands of 64 KiB before and after the output stay untouched by every kernel choice (the walk kernel's
-    lanes without a sample store to a scratch area of the plan, the rows kernel pads its grid, tiles are masked)."""
+    """Guard bands of 64 KiB before and after the output stay untouched by every kernel choice (the span kernel masks the
+    lanes past a row, the rows kernel pads its grid, tiles are masked)."""
     import doppler_amd
     guard = 65536
     cases = [
         ([(300000 + 13, 5000.0)], 1024000, 3),                                      # rows kernel + ragged head and tail
-        ([(50000 + 17 * k, 333.0 + k) for k in range(10)], 48000, 3),               # walk kernel, leftover ranges
+        ([(50000 + 17 * k, 333.0 + k) for k in range(10)], 48000, 3),               # span kernel, leftover ranges
         ([(120001, 9876.543), (5000, 3.0), (70000, -1234.5)], 1024000, 4),          # tile kernel only
-        ([(3000000 + 77, 5001.0)], 1024000, 5),                                     # one long stretch forced onto the walk kernel
+        ([(3000000 + 77, 5001.0)], 1024000, 5),                                     # one long stretch forced onto the span kernel
     ]
     for segs, rate, variant in cases:
         for intype, outtype in (("i16", "i16"), ("f32", "i16"), ("i16", "f32")):
@@ -871,12 +858,14 @@ def test_stream_ring_over_several_contexts(ctx, orc):
 def test_legacy_i16_cast_wraps_like_a_2016_rustc(ctx, orc):
     """dpx_set_i16_cast(DPX_CAST_LEGACY_X86): `(x * 32767.0) as i16` as the x86-64 code of a 2016 rustc computed it
     (CVTTSS2SI, low 16 bits kept: clipping samples wrap; NaN and |x| >= 2^31 give 0) against the oracle's twin
-    (orc.set_i16_cast(1), itself cross-checked by tests/test_restatement.py) — block-wise operator, bulk plans (const and
-    track-shaped, which the legacy mode confines to the tile kernel), the pack operator; and back to saturation."""
+    (orc.set_i16_cast(1), itself cross-checked by tests/test_restatement.py) — block-wise operator, the pack operator, and
+    bulk plans on EVERY kernel (round 4: the cast is a launch-uniform flag of all of them, no longer a tile-kernel build):
+    rows kernel (5000 Hz), one-matrix span launch (5001 Hz), tile kernel (variant 4), a track-shaped span launch with
+    matrices of 2-13 rows (several windows per workgroup, second turns) and leftover blocks; and back."""
     import doppler_amd
     from doppler_amd import dsp
     rng = np.random.default_rng(99)
-    n = 3 * 2048 + 77 + (1 << 16)
+    n = 3 * 2048 + 77 + (1 << 20)
     xi = make_iq("i16", n, 777, full_scale=True)                      # rotated full-scale samples clip
     f = make_iq("f32", n, 778).view(np.float32).copy()
     f[: n // 2] *= rng.choice([1.5, 3.0, 70.0, 7e4, 3e9, 1e30], size=n // 2).astype(np.float32)
@@ -898,11 +887,26 @@ def test_legacy_i16_cast_wraps_like_a_2016_rustc(ctx, orc):
                     assert sn == sn_w
                     assert_same_bytes(got, want, "i16", "legacy=%d block-wise %s->i16" % (legacy, intype))
                     pos += 8192
-                # bulk: const (rows kernel by default; tile kernel in the legacy mode) and a track-shaped plan
-                want, sn_w = orc.const_stream(x, intype, "i16", 5000, 1024000)
-                got, fin = run_bulk(ctx, x, intype, "i16", [(n, 5000.0)], 1024000)
+                # bulk: the rows kernel, a one-matrix span launch, the tile kernel — the same plans in both modes
+                for shift, variant, kern in ((5000, 3, "rows_launches"), (5001, 3, "walk_launches"), (5001, 4, "tile_launches")):
+                    assert doppler_amd.plan_layout([(n, float(shift))], 1024000, variant=variant)[kern] == 1
+                    want, sn_w = orc.const_stream(x, intype, "i16", shift, 1024000)
+                    ctx.set_tuning(0, 0, variant)
+                    try:
+                        got, fin = run_bulk(ctx, x, intype, "i16", [(n, float(shift))], 1024000)
+                    finally:
+                        ctx.set_tuning(0, 0, 3)
+                    assert fin == sn_w
+                    assert_same_bytes(got, want, "i16", "legacy=%d const bulk %s->i16 %d Hz variant %d" % (legacy, intype, shift, variant))
+                # track-shaped: nine matrices of 2..13 rows of one period (8192 at 262 144 Hz) with ragged last rows
+                tsegs = [((2 + (5 * k) % 12) * 8192 + 1000 * (k % 3), 32.0 * (2 * k + 1)) for k in range(9)]
+                tn = sum(c for c, _ in tsegs)
+                assert tn <= n and doppler_amd.plan_layout(tsegs, 262144)["walk_matrices"] >= 5
+                xt = x[:tn * (4 if intype == "i16" else 8)]
+                want, sn_w = orc.segments_stream(xt, intype, "i16", tsegs, 262144)
+                got, fin = run_bulk(ctx, xt, intype, "i16", tsegs, 262144)
                 assert fin == sn_w
-                assert_same_bytes(got, want, "i16", "legacy=%d const bulk %s->i16" % (legacy, intype))
+                assert_same_bytes(got, want, "i16", "legacy=%d track-shaped %s->i16" % (legacy, intype))
                 want, sn_w = orc.segments_stream(x, intype, "i16", segs, 48000)
                 got, fin = run_bulk(ctx, x, intype, "i16", segs, 48000)
                 assert fin == sn_w
@@ -912,8 +916,6 @@ def test_legacy_i16_cast_wraps_like_a_2016_rustc(ctx, orc):
                 orc.set_i16_cast(legacy)
                 differs = differs or not np.array_equal(sat, want)
             assert differs == bool(legacy)                            # the inputs do exercise the corner
-            lay = doppler_amd.plan_layout([(n, 5000.0)], 1024000)
-            assert lay["rows_launches"] == 1                          # (the layout query is the default plan either way)
             # the un-fused pack operator
             z = np.zeros(16, dtype=orc.complex32)
             z["re"][:8] = [1.2, -1.3, 0.5, 70000.0 / 32767, np.nan, np.inf, -np.inf, 3e9]

@@ -66,6 +66,24 @@ def test_restated_sincosf_matches_libm(orc):
     assert a.tobytes() != c.tobytes()     # these arguments are exactly where the two libm builds differ
 
 
+def test_device_reductions_proved_by_enumeration_on_the_cpu_model(tmp_path):
+    """The device sincos (doppler_amd/csrc/dpx_sincos.h, round 4) rounds the quadrant with a fused multiply-add against
+    1.5 * 2^52 and reduces 120 <= |theta| < 2^30 with a three-term double-precision 2/pi instead of glibc's integer
+    product.  Neither is glibc's operation sequence; both must give glibc's floats.  tests/extended/sincos_model.c
+    restates the two reductions with the IEEE double operations the device executes and enumerates EVERY argument of
+    their ranges (both signs, both libm builds) against the restated glibc sincosf: no mismatch allowed.  (The device
+    itself is enumerated on the GPU box: tests/extended/exhaustive_device_sincos.py.)"""
+    exe = str(tmp_path / "sincos_model")
+    fma = ["-mfma"] if "fma" in open("/proc/cpuinfo").read().split() else []
+    subprocess.check_call(["gcc", "-O2", *fma, "-ffp-contract=off", "-I" + os.path.join(ROOT, "oracle"), "-o", exe,
+                           os.path.join(ROOT, "tests", "extended", "sincos_model.c"), os.path.join(ROOT, "oracle", "sincosf_glibc.c"),
+                           "-lm", "-lpthread"])
+    for args in (["--v", "1"], ["--v", "0"], ["--plain", "--v", "1", "--lo", "0x39800000", "--hi", "0x42f00000"],
+                 ["--plain", "--v", "0", "--lo", "0x39800000", "--hi", "0x42f00000"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True)
+        assert r.returncode == 0 and "mismatches=0 " in r.stdout, r.stdout + r.stderr
+
+
 def test_restated_expf_and_cexpf_match_libm(orc):
     """Restated glibc expf (strided sweep of all floats; the exhaustive run is in DESIGN.md) and cexpf
     (random pairs + overflow/underflow/inf/nan corners) against this host's libm."""
