@@ -197,8 +197,41 @@ def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True):
     return line
 
 
+def device_identity(dev_index):
+    """What tells two ranks' GPUs apart in a SCALE record: PCI bus id (hipDeviceGetPCIBusId), the GPU's NUMA node, name."""
+    info = {"device": dev_index}
+    try:
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        buf = C.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, dev_index) == 0:
+            info["pci_bus_id"] = buf.value.decode()
+            numa = "/sys/bus/pci/devices/%s/numa_node" % info["pci_bus_id"].lower()
+            if os.path.exists(numa):
+                info["numa_node"] = int(open(numa).read().strip())
+    except Exception as e:   # identification only
+        info["pci_bus_id_error"] = str(e)[:100]
+    try:
+        info["name"] = torch.cuda.get_device_properties(dev_index).name
+    except Exception:
+        pass
+    return info
+
+
+def per_rank_report(rank, dev_index, avg_kernel_ms, elapsed_s):
+    """Every rank's own figures, gathered on rank 0 (all_gather_object): a SCALE line then shows the skew between the
+    GPUs, not only the slowest one."""
+    mine = dict(device_identity(dev_index), rank=rank, avg_kernel_ms=round(avg_kernel_ms, 4), timed_region_s=round(elapsed_s, 5),
+                pid=os.getpid(), cpu_affinity=len(os.sched_getaffinity(0)))
+    if not DIST_ON:
+        return [mine]
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine)
+    return everyone
+
+
 GATHER_TIMEOUT_S = 240
-PMC_PROFILE = "r03_pmc_traffic.json"     # tools/profile_r03.sh: separate FETCH_SIZE / WRITE_SIZE passes + a kernel-trace pass
+PMC_PROFILE = "r04_pmc_traffic.json"     # tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes + a kernel-trace pass
 KERNEL_SOURCES = ["doppler_amd/csrc/dpx_kernels.hip", "doppler_amd/csrc/dpx_sincos.h", "doppler_amd/csrc/dpx_types.h"]
 
 
@@ -213,7 +246,7 @@ def kernel_source_sha():
 
 
 def profiled(workload):
-    """PMC traffic and rocprofv3 kernel-trace duration of the dominant kernel from profiles/ (tools/profile_r03.sh),
+    """PMC traffic and rocprofv3 kernel-trace duration of the dominant kernel from profiles/ (tools/profile_round.sh),
     or None when the committed profile was taken on different kernel sources."""
     path = os.path.join(ROOT, "profiles", PMC_PROFILE)
     if not os.path.exists(path):
@@ -225,7 +258,7 @@ def profiled(workload):
     return pj.get(workload)
 
 
-def build_result(args, world, n, elapsed, avg_kernel_ms, gather, plan_ms=None, one_shot_ms=None):
+def build_result(args, world, n, elapsed, avg_kernel_ms, gather, plan_ms=None, one_shot_ms=None, per_rank=None):
     """The one JSON line of the headline workload (rank 0)."""
     achieved = n * BYTES_PER_SAMPLE / (avg_kernel_ms * 1e-3) / 1e9
     prof = profiled("const")
@@ -271,6 +304,14 @@ def build_result(args, world, n, elapsed, avg_kernel_ms, gather, plan_ms=None, o
     # what the process group really was: the driver's SCALE record can show that RCCL saw N ranks
     result["backend"] = dist.get_backend() if DIST_ON else None
     result["world_size_seen"] = dist.get_world_size() if DIST_ON else 1
+    if per_rank:
+        # rank by rank: the launch duration each GPU measured with its own HIP events, its wall time of the timed region, which
+        # physical device it was — `value` above is the max-over-ranks figure, this is what it is the max OF
+        result["per_rank"] = per_rank
+        ks = [r["avg_kernel_ms"] for r in per_rank if r]
+        result["per_rank_kernel_ms"] = ks
+        if ks:
+            result["kernel_ms_spread"] = {"min": min(ks), "max": max(ks), "max_over_min": round(max(ks) / min(ks), 4)}
     if gather:
         result["gather"] = gather
     return result
@@ -377,6 +418,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     avg_kernel_ms = ev0.elapsed_time(ev1) / args.steps      # launch duration incl. the inter-launch gap
+    per_rank = per_rank_report(rank, dev_index, avg_kernel_ms, LEGS["timed"])
 
     # ---- outside the timed region: ordered gather (multi-GPU), host round trip, CPU baseline
     gather = None
@@ -397,7 +439,7 @@ def main():
             os._exit(0)
 
         def result_line(g):
-            return build_result(args, world, n, elapsed, avg_kernel_ms, g, round(plan_ms, 3), round(one_shot_ms, 3))
+            return build_result(args, world, n, elapsed, avg_kernel_ms, g, round(plan_ms, 3), round(one_shot_ms, 3), per_rank)
 
         timer = threading.Timer(GATHER_TIMEOUT_S, give_up)
         timer.daemon = True
@@ -410,6 +452,20 @@ def main():
             tg = time.perf_counter() - tg
             gather = {"what": "RCCL send/recv of every rank's output chunk into rank 0, in rank order (not in `value`)",
                       "ms": round(tg * 1e3, 3), "GB_per_s_into_rank0": round((world - 1) * 4 * n / tg / 1e9, 2)}
+            # peer by peer, one transfer at a time: what each link into rank 0 gives on its own (a slow or indirect xGMI
+            # path shows here; the batch above shows what they give together)
+            per_peer = []
+            for peer in range(1, world):
+                barrier()
+                tp = time.perf_counter()
+                if rank == peer:
+                    dist.send(out, 0)
+                elif rank == 0:
+                    dist.recv(buf[2 * n * peer:2 * n * (peer + 1)], peer)
+                barrier()
+                tp = time.perf_counter() - tp
+                per_peer.append({"peer": peer, "ms": round(tp * 1e3, 3), "GB_per_s": round(4 * n / tp / 1e9, 2)})
+            gather["per_peer"] = per_peer
             del buf
         except Exception as e:   # reported, not fatal: the headline does not depend on the gather
             gather = {"error": str(e)[:300]}
@@ -438,7 +494,7 @@ def main():
 
     result = None
     if rank == 0:
-        result = build_result(args, world, n, elapsed, avg_kernel_ms, gather, round(plan_ms, 3), round(one_shot_ms, 3))
+        result = build_result(args, world, n, elapsed, avg_kernel_ms, gather, round(plan_ms, 3), round(one_shot_ms, 3), per_rank)
         if world == 1:
             # PCIe-inclusive figure (never `value`): pinned host -> HBM -> kernel -> pinned host
             t_leg = time.perf_counter()

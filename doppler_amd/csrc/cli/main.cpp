@@ -184,6 +184,14 @@ bool write_all(int fd, const char *p, size_t n, bool positioned, off_t off)
 // taken it; the pipe holds at most `slots` pages, every piece starts on a page of its own, so a page that lies more than
 // `slots` pages behind the write position has left the pipe — the ring is four times that long.  (The pinned output slab
 // itself is never lent: it is recycled at once, and its pages belong to the GPU runtime.)
+//
+// OPT-IN (DOPPLER_VMSPLICE=1; round 4).  vmsplice gives no completion signal, and "has left doppler's pipe" is not "has been
+// consumed": a reader that forwards pipe buffers by reference — splice() into another pipe or a socket, tee(2); `pv` does
+// so by default — keeps pointing at ring pages after they left this pipe, and a downstream queue longer than the ring's
+// slack (a later stage that enlarged its own pipe while ours stayed at 64 KiB) would see them overwritten: silent
+// corruption.  The reference writes with a plain `stdout.write` (src/main.rs:86,92) and has no such hazard, so that is
+// the default here too; lending is for pipelines whose next stage is known to COPY (read()), where it is worth 2-5 x
+// (profiles/r03_cli.md).  Even then it is refused when the output pipe could not be grown beyond the default 64 KiB.
 class PipeLender {
 public:
     bool open(int fd, long pipe_bytes)
@@ -231,7 +239,11 @@ public:
                 const ssize_t w = vmsplice(fd_, &iov, 1, 0);
                 if (w < 0) {
                     if (errno == EINTR) continue;
-                    if (first_ && (errno == EINVAL || errno == ENOSYS || errno == EBADF)) { *unsupported = true; return false; }
+                    if (first_ && (errno == EINVAL || errno == ENOSYS || errno == EBADF)) {
+                        *unsupported = true;
+                        ring_ = nullptr;                                  // not lending from now on: active() says so, no further attempts
+                        return false;
+                    }
                     return false;
                 }
                 first_ = false;
@@ -520,7 +532,11 @@ int main(int argc, char **argv)
     }
 
     PipeLender lender;
-    if (pipe_out > 0 && !getenv("DOPPLER_NO_VMSPLICE")) (void)lender.open(STDOUT_FILENO, pipe_out);
+    {
+        // lending pages to the output pipe: only when asked for, and only into a pipe that did grow (see PipeLender)
+        const char *e = getenv("DOPPLER_VMSPLICE");
+        if (pipe_out > 65536 && e && atoi(e) != 0 && !getenv("DOPPLER_NO_VMSPLICE")) (void)lender.open(STDOUT_FILENO, pipe_out);
+    }
     // ---- consumer: oldest slab -> stdout.  Pipe: write here, in order.  File: hand the slab to a drain worker with
     // its offset; the recycling (dpx_stream_release, in order) happens as the oldest writes complete.
     std::thread consumer([&]() {

@@ -9,6 +9,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -567,7 +570,20 @@ int dpx_shift_block_async(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_
         if (plan.error) return fail(DPX_ERR_PLAN, "%s", plan.error);
         const size_t seg_bytes = align256(plan.segs.size() * sizeof(dpx::DevSeg));
         const size_t hint_bytes = plan.hint.size() * sizeof(uint32_t);
-        if (plan.lut_entries != 0 || seg_bytes + hint_bytes > kSmallPlanBytes) return fail(DPX_ERR_PLAN, "block plan exceeds its slot");
+        if (plan.lut_entries != 0 || seg_bytes + hint_bytes > kSmallPlanBytes) {
+            // The block's plan wants a corrector table (periods below 4: shift 0, samplerate / 2 ...; the reference resets the
+            // counter on every sample there) or has more stretches than a slot holds: this block takes the synchronous path
+            // into the slot's output buffer — same bytes, same ticket protocol, no overlap for this one block.
+            uint32_t sn_sync = *samplenum;
+            const int rc = run_host(ctx, in, n, in_fmt, a.host + kSmallOutOff, out_fmt, &sn_sync, shift_hz, samplerate);
+            if (rc != DPX_OK) return rc;
+            DPX_HIP(hipEventRecord(a.done, ctx->stream));
+            a.seq = seq;
+            ctx->async_next_seq = seq + 1 == 0 ? 1 : seq + 1;
+            *samplenum = sn_sync;
+            *ticket = seq;
+            return DPX_OK;
+        }
         memcpy(a.host + kSmallInOff, in, in_bytes);
         memcpy(a.host + kSmallPlanOff, plan.segs.data(), plan.segs.size() * sizeof(dpx::DevSeg));
         memcpy(a.host + kSmallPlanOff + seg_bytes, plan.hint.data(), hint_bytes);
@@ -593,7 +609,11 @@ int dpx_wait(dpx_ctx *ctx, dpx_ticket ticket, void *out, size_t out_cap, size_t 
     if (a.seq != ticket) return fail(DPX_ERR_ARG, "ticket %u is not in flight", ticket);
     if (a.out_bytes > out_cap || (!out && a.out_bytes))
         return fail(DPX_ERR_CAPACITY, "output needs %zu bytes, capacity %zu", a.out_bytes, out_cap);
-    DPX_HIP(hipEventSynchronize(a.done));
+    const hipError_t e = hipEventSynchronize(a.done);
+    if (e != hipSuccess) {
+        a.seq = 0;                  // the slot is free again whatever happened to its block
+        return fail(DPX_ERR_HIP, "waiting for ticket %u: %s", ticket, hipGetErrorString(e));
+    }
     if (a.out_bytes) memcpy(out, a.host + kSmallOutOff, a.out_bytes);
     if (n_samples_out) *n_samples_out = a.n_samples;
     a.seq = 0;
@@ -1008,6 +1028,7 @@ struct dpx_stream_slab {
     void *d_in = nullptr, *d_out = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
+    int numa_node = -1;          // where the pinned buffers were placed (-1: the caller's default policy)
     dpx::PlanResult plan;
     DevPlan dev;
     size_t out_bytes = 0;
@@ -1030,6 +1051,46 @@ struct dpx_stream {
     std::atomic<int> in_flight{0};
     dpx_stream_stats stats = {};   // host cost of dpx_stream_submit, by part (dpx_stream_get_stats)
 };
+
+namespace {
+
+// NUMA node of a GPU's PCIe root (sysfs, through the device's PCI bus id), or -1.  An 8-GPU MI355X node has two sockets,
+// four GPUs under each: a slab ring whose pinned buffers all come from the creating thread's node sends half of the
+// D2H traffic (8 x 25-28 GB/s at the kernel's rate) across the socket link.
+int gpu_numa_node(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) return -1;
+    for (char *c = bus; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    char path[128];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
+// Pinned allocations of the calling thread prefer `node` until the policy is reset (node < 0: the default policy).
+// set_mempolicy(2) by number: no libnuma in the image; failure (no NUMA, seccomp) is silent — the default policy stays.
+void prefer_numa_node(int node)
+{
+#ifdef SYS_set_mempolicy
+    constexpr int kMpolDefault = 0, kMpolPreferred = 1;
+    if (node < 0 || node >= 1024) {
+        (void)syscall(SYS_set_mempolicy, kMpolDefault, nullptr, 0);
+        return;
+    }
+    unsigned long mask[1024 / (8 * sizeof(unsigned long))] = {0};
+    mask[(size_t)node / (8 * sizeof(unsigned long))] |= 1ul << ((size_t)node % (8 * sizeof(unsigned long)));
+    (void)syscall(SYS_set_mempolicy, kMpolPreferred, mask, 1024 + 1);
+#else
+    (void)node;
+#endif
+}
+
+}  // namespace
 
 int dpx_stream_create_multi(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_fmt, uint32_t samplerate,
                             uint32_t samplenum0, size_t slab_bytes, int slabs_per_ctx, dpx_stream **out)
@@ -1058,9 +1119,18 @@ int dpx_stream_create_multi(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out
         dpx_stream_slab &b = s->slabs[k];
         b.ctx = ctxs[k % (size_t)n_ctx];                 // consecutive slabs on consecutive GPUs: their copies and kernels overlap
         hipError_t e = hipSetDevice(b.ctx->device);
+        // A slab's pinned buffers live on the NUMA node of ITS GPU (several GPUs only: one GPU's ring stays where its caller
+        // runs): the pages are taken while the buffer is pinned, under this thread's policy.
+        const int node = n_ctx > 1 ? gpu_numa_node(b.ctx->device) : -1;
+        b.numa_node = node;
+        if (node >= 0) prefer_numa_node(node);
         // portable: pinned for every device of the process, so that any slab can be handed to any GPU's DMA engines
         if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_in), slab_bytes, hipHostMallocPortable);
         if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_out), s->slab_out + 16, hipHostMallocPortable);
+        if (node >= 0) {
+            if (e == hipSuccess) { memset(b.h_in, 0, slab_bytes); memset(b.h_out, 0, s->slab_out + 16); }   // first touch under the policy, in case pinning left any page untouched
+            prefer_numa_node(-1);
+        }
         if (e == hipSuccess) e = hipMalloc(&b.d_in, slab_bytes);
         if (e == hipSuccess) e = hipMalloc(&b.d_out, s->slab_out + 16);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking);

@@ -926,6 +926,33 @@ def test_legacy_i16_cast_wraps_like_a_2016_rustc(ctx, orc):
         orc.set_i16_cast(0)
 
 
+def test_async_blocks_whose_plan_wants_a_table(ctx, orc):
+    """dpx_shift_block_async with shifts whose period is below 4 — shift 0 (the reference resets the counter on EVERY sample:
+    period 1), samplerate / 2 (period 2), samplerate / 3 — and an ordinary shift between them: such a block's plan asks for
+    a corrector table, which the asynchronous slot has no room for; it takes the synchronous path inside the call (round 3
+    returned DPX_ERR_PLAN: a drop-in for the loop of main.rs:113-118 must take every input the loop takes).  Both block
+    formats, tickets in flight across the fallback, counters carried, against the oracle block by block."""
+    from doppler_amd import dsp
+    rate = 48000
+    shifts = [0.0, 5000.0, 24000.0, 0.0, 16000.0, -24000.0, 123.0, 0.0]
+    for intype, outtype, per in (("i16", "i16", 2048), ("f32", "i16", 1024), ("i16", "f32", 2048)):
+        x = make_iq(intype, per * len(shifts) - 100, 77)          # the last block is short
+        bs = 8192
+        sn, sn_w, tickets, got, want = 3, 3, [], [], []
+        for b, hz in enumerate(shifts):
+            blk = x[b * bs:(b + 1) * bs]
+            tk, sn = dsp.shift_block_async(blk, intype, outtype, sn, hz, rate, ctx=ctx)
+            w, _, _, sn_w = orc.shift_block(blk, intype, outtype, sn_w, hz, rate)
+            assert sn == sn_w, (b, hz)
+            want.append(w)
+            tickets.append(tk)
+            if len(tickets) == 3:
+                got.append(dsp.wait(tickets.pop(0), outtype, ctx=ctx))
+        while tickets:
+            got.append(dsp.wait(tickets.pop(0), outtype, ctx=ctx))
+        assert_same_bytes(np.concatenate(got), np.concatenate(want), outtype, "async blocks with tiny periods %s->%s" % (intype, outtype))
+
+
 def test_async_blocks_equal_the_synchronous_path_on_the_golden_track_replay(ctx, orc):
     """dpx_shift_block_async / dpx_wait (the loop of main.rs:113-118 with block k + 1 read while block k is on the GPU): the
     golden track replay block by block with two, then four blocks in flight — bytes and counters of the synchronous path

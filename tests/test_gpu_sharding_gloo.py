@@ -105,22 +105,28 @@ def test_ranks_call_the_kernel_then_ordered_gather(world):
         assert ok, name
 
 
-def test_bench_multi_rank_code_path_on_a_shared_gpu():
-    """bench.py --gpus 2 exactly as the driver launches it, except that both ranks share GPU 0 over gloo
-    (DPX_BENCH_SHARE_GPU=1): chunk seeds, barrier + max-over-ranks timing, the gather leg, one JSON line from rank 0.
-    The numbers of such a run mean nothing and are not asserted."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_multi_rank_code_path_on_a_shared_gpu(world):
+    """bench.py --gpus 2 and --gpus 8 exactly as the driver launches them, except that the ranks share GPU 0 over gloo
+    (DPX_BENCH_SHARE_GPU=1; 8 x 2 GiB of streams + the 8 GiB gather buffer fit one MI355X): chunk seeds, barrier +
+    max-over-ranks timing, the gather leg batched and peer by peer, every rank's own kernel time and device identity in
+    the ONE JSON line from rank 0.  The numbers of such a run mean nothing and are not asserted."""
     env = dict(os.environ, DPX_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29700 + (os.getpid() % 200)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    port = 29700 + (os.getpid() % 200) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["n_gpus"] == world and line["steps"] == 3 and line["scaling"] == "weak" and line["world_size_seen"] == world
     assert line["config"]["samples_per_gpu"] == 268435456
-    assert "roofline" in line and "gather" in line
+    assert "roofline" in line and "gather" in line and "error" not in line["gather"], line.get("gather")
+    assert [r_["rank"] for r_ in line["per_rank"]] == list(range(world)) and len(line["per_rank_kernel_ms"]) == world
+    assert all(r_["avg_kernel_ms"] > 0 and "pci_bus_id" in r_ for r_ in line["per_rank"]), line["per_rank"]
+    assert [p["peer"] for p in line["gather"]["per_peer"]] == list(range(1, world))
+    assert "error" not in line["gather"]["per_gpu_d2h"], line["gather"]["per_gpu_d2h"]
 
 
 def test_bench_rccl_branch_with_one_rank():
@@ -139,6 +145,7 @@ def test_bench_rccl_branch_with_one_rank():
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
     assert line["backend"] == "nccl" and line["world_size_seen"] == 1 and line["n_gpus"] == 1
+    assert len(line["per_rank"]) == 1 and line["per_rank"][0]["avg_kernel_ms"] > 0 and "pci_bus_id" in line["per_rank"][0]
     assert "error" not in line["gather"] and "error" not in line["gather"]["per_gpu_d2h"], line["gather"]
     assert line["gather"]["ms"] > 0 and line["roofline"]["frac"] > 0.5
     # and the track workload's barrier / all_reduce under the same process group

@@ -20,7 +20,7 @@ run "cat file | doppler | cat > /dev/null (64 KiB pipes kept: DOPPLER_NO_PIPE_GR
 run "cat file | doppler | cat > /dev/null" "cat /dev/shm/dpx_pipes_in.iq" "cat > /dev/null" ""
 run "dd bs=8M | doppler | dd bs=8M of=/dev/null" "dd if=/dev/shm/dpx_pipes_in.iq bs=8M 2>/dev/null" "dd of=/dev/null bs=8M 2>/dev/null" ""
 run "pipe_source (write) | doppler | pipe_sink (read)" "tools/bin/pipe_source $N" "tools/bin/pipe_sink" ""
-run "pipe_source (vmsplice) | doppler | pipe_sink (splice)" "tools/bin/pipe_source $N vmsplice" "tools/bin/pipe_sink splice" ""
+run "pipe_source (vmsplice) | doppler (DOPPLER_VMSPLICE=1) | pipe_sink (splice)" "tools/bin/pipe_source $N vmsplice" "tools/bin/pipe_sink splice" "DOPPLER_VMSPLICE=1"
 echo "== input side alone: pipe_source (vmsplice) | doppler > /dev/null" >> $OUT
 ( tools/bin/pipe_source $N vmsplice | env DOPPLER_STATS=1 $EXE $ARGS > /dev/null ) 2>> $OUT
 echo "== output side alone: doppler < file | pipe_sink (splice)" >> $OUT
