@@ -42,7 +42,7 @@ $(LIB): $(OBJS)
 BINDIR := doppler_amd/bin
 cli: $(BINDIR)/doppler
 
-$(BINDIR)/doppler: $(CSRC)/cli/main.cpp $(CSRC)/cli/args.cpp $(CSRC)/cli/args.h include/doppler_hip.h include/doppler_hip_debug.h include/doppler_hip_host.h $(LIB)
+$(BINDIR)/doppler: $(CSRC)/cli/main.cpp $(CSRC)/cli/args.cpp $(CSRC)/cli/args.h $(CSRC)/host/orbit.h $(CSRC)/host/schedule.h include/doppler_hip.h include/doppler_hip_debug.h include/doppler_hip_host.h $(LIB)
 	@mkdir -p $(BINDIR)
 	g++ -O2 -std=c++17 -ffp-contract=off -Wall -pthread -Iinclude $(CSRC)/cli/main.cpp $(CSRC)/cli/args.cpp \
 	    -o $@ -L$(LIBDIR) -ldoppler_hip -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,$(ROCM)/lib

@@ -445,13 +445,18 @@ def main():
         timer.daemon = True
         timer.start()
         try:
+            # (development mode on a shared GPU: gloo stages device tensors through host sockets at ~0.1 GB/s — a 64 MiB piece
+            # per rank exercises the same code in seconds; under RCCL the whole chunk moves)
+            ng = n if not share else min(n, 1 << 24)
+            og = out[: 2 * ng]
             barrier()
             tg = time.perf_counter()
-            buf = shard.ordered_gather(out, [2 * n] * world, dst=0)
+            buf = shard.ordered_gather(og, [2 * ng] * world, dst=0)
             barrier()
             tg = time.perf_counter() - tg
             gather = {"what": "RCCL send/recv of every rank's output chunk into rank 0, in rank order (not in `value`)",
-                      "ms": round(tg * 1e3, 3), "GB_per_s_into_rank0": round((world - 1) * 4 * n / tg / 1e9, 2)}
+                      "bytes_per_rank": 4 * ng,
+                      "ms": round(tg * 1e3, 3), "GB_per_s_into_rank0": round((world - 1) * 4 * ng / tg / 1e9, 2)}
             # peer by peer, one transfer at a time: what each link into rank 0 gives on its own (a slow or indirect xGMI
             # path shows here; the batch above shows what they give together)
             per_peer = []
@@ -459,12 +464,12 @@ def main():
                 barrier()
                 tp = time.perf_counter()
                 if rank == peer:
-                    dist.send(out, 0)
+                    dist.send(og, 0)
                 elif rank == 0:
-                    dist.recv(buf[2 * n * peer:2 * n * (peer + 1)], peer)
+                    dist.recv(buf[2 * ng * peer:2 * ng * (peer + 1)], peer)
                 barrier()
                 tp = time.perf_counter() - tp
-                per_peer.append({"peer": peer, "ms": round(tp * 1e3, 3), "GB_per_s": round(4 * n / tp / 1e9, 2)})
+                per_peer.append({"peer": peer, "ms": round(tp * 1e3, 3), "GB_per_s": round(4 * ng / tp / 1e9, 2)})
             gather["per_peer"] = per_peer
             del buf
         except Exception as e:   # reported, not fatal: the headline does not depend on the gather

@@ -142,6 +142,11 @@ long grow_pipe(int fd, bool grow = true)
         if (fscanf(f, "%ld", &v) == 1 && v > 0) cap = v;
         fclose(f);
     }
+    // DOPPLER_PIPE_BYTES=N: ask for that much and no more (a pipeline that wants small buffers; the tests)
+    if (const char *e = getenv("DOPPLER_PIPE_BYTES")) {
+        const long v = atol(e);
+        if (v >= (64 << 10)) { (void)fcntl(fd, F_SETPIPE_SZ, (int)std::min(v, cap)); return fcntl(fd, F_GETPIPE_SZ); }
+    }
     // a privileged process may go beyond pipe-max-size: try 16 MiB first, then the limit, then halves of it
     for (long want : {16L << 20, cap, cap / 2, cap / 4})
         if (want >= (64 << 10) && fcntl(fd, F_SETPIPE_SZ, (int)want) >= 0) break;

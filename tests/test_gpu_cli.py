@@ -372,7 +372,7 @@ def test_an_existing_longer_output_file_keeps_its_tail_and_a_full_disk_is_a_writ
 def test_output_lent_to_a_pipe_that_the_reader_enlarges(orc):
     """With DOPPLER_VMSPLICE=1 the output side lends staging pages to the pipe (vmsplice) and reuses a page only when it has
     left the pipe, which depends on the pipe's capacity — and the READER may change that at any time.  Here the reader
-    stalls, enlarges the pipe doppler had grown to 4 MiB, stalls again and only then drains: the bytes must be the oracle's
+    stalls, enlarges the pipe doppler had grown to 256 KiB (DOPPLER_PIPE_BYTES) to 1 MiB, stalls again and only then drains: the bytes must be the oracle's
     (a ring sized for the smaller pipe would have been overwritten under the queued pages).  Lending is OPT-IN (a reader
     that forwards pipe buffers by reference would see reused pages; the reference's plain write has no such hazard):
     without the variable, and into a pipe that stayed at 64 KiB, the output is written."""
@@ -382,7 +382,7 @@ def test_output_lent_to_a_pipe_that_the_reader_enlarges(orc):
     want, _ = orc.const_stream(x, "i16", "i16", 5000, rate, threads=4)
     reader = ("import sys, time, fcntl, os\n"
               "time.sleep(0.3)\n"
-              "fcntl.fcntl(0, 1031, 1 << 22)\n"            # F_SETPIPE_SZ
+              "fcntl.fcntl(0, 1031, 1 << 20)\n"            # F_SETPIPE_SZ
               "time.sleep(0.5)\n"
               "out = open(sys.argv[1], 'wb')\n"
               "while True:\n"
@@ -401,7 +401,7 @@ def test_output_lent_to_a_pipe_that_the_reader_enlarges(orc):
                                    stderr=subprocess.PIPE, env=env, timeout=300)
             assert r.returncode == 0 and b"vmsplice" not in r.stderr, r.stderr[-500:]
             assert_same_bytes(np.frombuffer(r.stdout, dtype=np.uint8), want, "i16", "written output %r" % (extra,))
-        env = dict(os.environ, DOPPLER_VMSPLICE="1", DOPPLER_STATS="1", DOPPLER_SLAB_BYTES="262144")
+        env = dict(os.environ, DOPPLER_VMSPLICE="1", DOPPLER_PIPE_BYTES="262144", DOPPLER_STATS="1", DOPPLER_SLAB_BYTES="262144")
         with open(src, "rb") as fi:
             p1 = subprocess.Popen([EXE, "const", "-s", str(rate), "-i", "i16", "--shift", "5000"], stdin=fi, stdout=subprocess.PIPE,
                                   stderr=subprocess.PIPE, env=env)
