@@ -101,6 +101,8 @@ _SIGNATURES = {
     "dpx_plan_const": (_i, [_vp, _f, _u32, _u32, _u64, _P(_vp)]),
     "dpx_plan_segments": (_i, [_vp, _P(Segment), _sz, _u32, _u32, _P(_vp)]),
     "dpx_plan_n_samples": (_i, [_vp, _P(_u64)]),
+    "dpx_set_resident": (_i, [_vp, _i]),
+    "dpx_resident_stats": (_i, [_vp, _P(_u64), _P(_u64)]),
     "dpx_plan_final_samplenum": (_i, [_vp, _P(_u32)]),
     "dpx_plan_destroy": (None, [_vp]),
     "dpx_stream_create": (_i, [_vp, _i, _i, _u32, _u32, _sz, _i, _P(_vp)]),

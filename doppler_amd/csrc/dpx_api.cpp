@@ -7,6 +7,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <sys/syscall.h>
@@ -79,9 +80,19 @@ struct dpx_ctx {
         hipEvent_t done = nullptr;
         uint32_t seq = 0;            // ticket of the block the slot holds (0: free)
         size_t out_bytes = 0, n_samples = 0;
+        bool resident = false;       // the block was handed to the resident kernel (completion word), not launched (event)
     } async_slots[kAsyncSlots];
     uint32_t async_next_seq = 1;
+    // the resident block kernel (dpx_types.h, BlockCtl): one workgroup per slot, launched once, polling the slots' doorbells
+    bool resident_on = true;         // DPX_RESIDENT=0 or dpx_set_resident(ctx, 0): every block is a launch, as in round 3
+    bool resident_running = false;   // host's view: a kernel has been launched and not yet seen parked
+    int resident_in = -1, resident_out = -1;
+    bool resident_fma = true;
+    hipStream_t rstream = nullptr;
+    dpx::ResidentShared *rshared = nullptr;
+    uint64_t resident_launches = 0, resident_blocks = 0;
 };
+static_assert(dpx_ctx::kAsyncSlots == dpx::kResidentSlots, "one resident workgroup per staging slot");
 
 // device image of a plan: stretch table | hint table | corrector-table pool, one allocation
 struct DevPlan {
@@ -269,6 +280,149 @@ void release(DevPlan &dev)
 constexpr size_t kSmallCallBytes = 64 << 10;      // per side; larger calls go through device staging buffers
 constexpr size_t kSmallPlanBytes = 16 << 10;
 constexpr size_t kSmallInOff = 0, kSmallOutOff = kSmallCallBytes, kSmallPlanOff = 2 * kSmallCallBytes;
+constexpr size_t kSmallCtlOff = 2 * kSmallCallBytes + kSmallPlanBytes;      // dpx::BlockCtl of an asynchronous slot
+constexpr size_t kSlotBytes = kSmallCtlOff + 256;
+constexpr uint64_t kResidentIdleTicks = 200000;       // 2 ms of the 100 MHz wall clock without a block: the kernel leaves
+constexpr double kResidentTimeoutS = 5.0;             // a completion word that does not come: error, resident mode off
+
+inline dpx::BlockCtl *slot_ctl(dpx_ctx::AsyncSlot &a) { return reinterpret_cast<dpx::BlockCtl *>(a.host + kSmallCtlOff); }
+inline uint32_t load_acq(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+inline void store_rel(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+inline double mono_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline void cpu_relax()
+{
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
+
+int alloc_slot(dpx_ctx::AsyncSlot &a)
+{
+    if (a.host) return DPX_OK;
+    void *h = nullptr, *d = nullptr;
+    DPX_HIP(hipHostMalloc(&h, kSlotBytes, hipHostMallocMapped));
+    hipError_t e = hipHostGetDevicePointer(&d, h, 0);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&a.done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)hipHostFree(h);
+        return fail(DPX_ERR_HIP, "asynchronous block slot: %s", hipGetErrorString(e));
+    }
+    memset(static_cast<char *>(h) + kSmallCtlOff, 0, 256);
+    a.host = static_cast<char *>(h);
+    a.dev = static_cast<char *>(d);
+    slot_ctl(a)->state = dpx::kResidentParked;
+    return DPX_OK;
+}
+
+bool resident_all_parked(dpx_ctx *ctx)
+{
+    for (auto &a : ctx->async_slots)
+        if (a.host && load_acq(&slot_ctl(a)->state) != dpx::kResidentParked) return false;
+    return true;
+}
+
+// Ask the resident kernel to leave and wait until it has: before any launch of this context's own (a resident kernel holds
+// its hardware queue; another stream's launch that shares the queue would wait for it), before the context goes away, and
+// when the format pair changes.  Blocks already rung are finished first.  Costs one load when no kernel is running.
+int resident_stop(dpx_ctx *ctx)
+{
+    if (!ctx->resident_running) return DPX_OK;
+    const double t0 = mono_s();
+    for (auto &a : ctx->async_slots) {             // blocks in flight: their completion words first
+        if (!a.host || !a.resident || a.seq == 0) continue;
+        dpx::BlockCtl *c = slot_ctl(a);
+        while (load_acq(&c->done) != a.seq && load_acq(&c->state) != dpx::kResidentParked && mono_s() - t0 < kResidentTimeoutS) cpu_relax();
+    }
+    for (auto &a : ctx->async_slots) {
+        if (!a.host) continue;
+        dpx::BlockCtl *c = slot_ctl(a);
+        if (a.resident && a.seq != 0 && load_acq(&c->done) != a.seq) continue;      // rung but unserved (the kernel left first): keep the ticket in the doorbell
+        store_rel(&c->doorbell, dpx::kDoorExit);
+    }
+    // (a slot whose doorbell still holds an unserved ticket cannot be told to leave through it: the idle clock takes that
+    // workgroup out within kResidentIdleTicks once the others have gone — it cannot happen unless the kernel left early)
+    while (!resident_all_parked(ctx)) {
+        if (mono_s() - t0 > kResidentTimeoutS) {
+            ctx->resident_on = false;
+            return fail(DPX_ERR_HIP, "the resident block kernel does not leave");
+        }
+        cpu_relax();
+    }
+    DPX_HIP(hipStreamSynchronize(ctx->rstream));
+    ctx->resident_running = false;
+    return DPX_OK;
+}
+
+// A resident kernel for (in_fmt, out_fmt) is polling every slot's doorbell when this returns.
+int resident_ensure(dpx_ctx *ctx, int in_fmt, int out_fmt)
+{
+    if (ctx->resident_running) {
+        const bool same = ctx->resident_in == in_fmt && ctx->resident_out == out_fmt && ctx->resident_fma == ctx->fma;
+        bool any_parked = false;
+        for (auto &a : ctx->async_slots) any_parked = any_parked || load_acq(&slot_ctl(a)->state) == dpx::kResidentParked;
+        if (same && !any_parked) return DPX_OK;
+        if (!same) {
+            const int rc = resident_stop(ctx);
+            if (rc != DPX_OK) return rc;
+        } else {
+            // the kernel is leaving (idle clock): its workgroups go within microseconds of each other
+            const double t0 = mono_s();
+            while (!resident_all_parked(ctx)) {
+                if (mono_s() - t0 > kResidentTimeoutS) {
+                    ctx->resident_on = false;
+                    return fail(DPX_ERR_HIP, "the resident block kernel does not leave");
+                }
+                cpu_relax();
+            }
+            DPX_HIP(hipStreamSynchronize(ctx->rstream));
+            ctx->resident_running = false;
+        }
+    }
+    for (auto &a : ctx->async_slots) {
+        const int rc = alloc_slot(a);
+        if (rc != DPX_OK) return rc;
+    }
+    if (!ctx->rstream) DPX_HIP(hipStreamCreateWithFlags(&ctx->rstream, hipStreamNonBlocking));
+    if (!ctx->rshared) DPX_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->rshared), sizeof(dpx::ResidentShared)));
+    DPX_HIP(hipMemsetAsync(ctx->rshared, 0, sizeof(dpx::ResidentShared), ctx->rstream));
+    dpx::ResidentArgs ra;
+    for (int k = 0; k < dpx_ctx::kAsyncSlots; ++k) {
+        dpx_ctx::AsyncSlot &a = ctx->async_slots[k];
+        dpx::BlockCtl *c = slot_ctl(a);
+        if (c->doorbell == dpx::kDoorExit) c->doorbell = c->done;       // a stop request of the past is not one for this launch
+        store_rel(&c->state, dpx::kResidentRunning);
+        ra.ctl[k] = reinterpret_cast<dpx::BlockCtl *>(a.dev + kSmallCtlOff);
+        ra.in[k] = reinterpret_cast<const uint8_t *>(a.dev + kSmallInOff);
+        ra.out[k] = reinterpret_cast<uint8_t *>(a.dev + kSmallOutOff);
+        ra.segs[k] = reinterpret_cast<const dpx::DevSeg *>(a.dev + kSmallPlanOff);
+    }
+    ra.shared = ctx->rshared;
+    ra.idle_ticks = kResidentIdleTicks;
+    const int rc = dpx::launch_resident_block(ra, in_fmt, out_fmt, ctx->fma, ctx->rstream);
+    if (rc != DPX_OK) {
+        for (auto &a : ctx->async_slots) slot_ctl(a)->state = dpx::kResidentParked;
+        return fail(rc, "resident block kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    ctx->resident_running = true;
+    ctx->resident_in = in_fmt;
+    ctx->resident_out = out_fmt;
+    ctx->resident_fma = ctx->fma;
+    ++ctx->resident_launches;
+    return DPX_OK;
+}
+
+// every entry point that launches or synchronises on this context's behalf passes through here first
+#define DPX_ENTER(ctx)                                              \
+    do {                                                            \
+        DPX_HIP(hipSetDevice((ctx)->device));                       \
+        if ((ctx)->resident_running) {                              \
+            const int rc_enter_ = resident_stop(ctx);               \
+            if (rc_enter_ != DPX_OK) return rc_enter_;              \
+        }                                                           \
+    } while (0)
 
 // One 8 KiB block per call is what the reference's loop does (main.rs:62-99).  For such calls the fixed costs decide:
 // no device staging, no hipMemcpy calls, no corrector tables (2048 samples do not pay for a table build) — the tile
@@ -317,7 +471,7 @@ int run_host_small(dpx_ctx *ctx, const void *in, size_t n, int in_fmt, void *out
 int run_host(dpx_ctx *ctx, const void *in, size_t n, int in_fmt, void *out, int out_fmt,
              uint32_t *samplenum, float shift_hz, uint32_t samplerate)
 {
-    DPX_HIP(hipSetDevice(ctx->device));
+    DPX_ENTER(ctx);
     if (n != 0 && n * 8 <= kSmallCallBytes && ctx->variant == 0) {
         const int rc = run_host_small(ctx, in, n, in_fmt, out, out_fmt, samplenum, shift_hz, samplerate);
         if (rc <= 0) return rc;
@@ -353,7 +507,7 @@ int run_host(dpx_ctx *ctx, const void *in, size_t n, int in_fmt, void *out, int 
 int run_host_segments(dpx_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt, uint32_t *samplenum,
                       const dpx_segment *segs, size_t n_segs, uint32_t samplerate)
 {
-    DPX_HIP(hipSetDevice(ctx->device));
+    DPX_ENTER(ctx);
     dpx::PlanResult plan;
     uint32_t sn = *samplenum;
     append_segments(plan, segs, n_segs, samplerate, sn, ctx->variant, ctx->periods);
@@ -422,6 +576,7 @@ int dpx_ctx_create(int device, dpx_ctx **out)
     if (!ctx) return fail(DPX_ERR_ARG, "out of host memory");
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *e = getenv("DPX_RESIDENT")) ctx->resident_on = atoi(e) != 0;
     hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (se != hipSuccess) {
         delete ctx;
@@ -447,6 +602,9 @@ void dpx_ctx_destroy(dpx_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)resident_stop(ctx);                   // the resident block kernel leaves before its slots are freed
+    if (ctx->rstream) { (void)hipStreamSynchronize(ctx->rstream); (void)hipStreamDestroy(ctx->rstream); }
+    if (ctx->rshared) (void)hipFree(ctx->rshared);
     if (ctx->stage_in) (void)hipFree(ctx->stage_in);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
     if (ctx->scratch) {
@@ -527,6 +685,20 @@ int dpx_shift_block(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt, v
     const size_t n = in_bytes / bytes_per_sample(in_fmt);
     if (n * bytes_per_sample(out_fmt) > out_cap || (!out && n))
         return fail(DPX_ERR_CAPACITY, "output needs %zu bytes, capacity %zu", n * bytes_per_sample(out_fmt), out_cap);
+    // a reference-sized block goes to the resident kernel when nothing is in flight there (a doorbell and a completion word
+    // instead of a launch and a stream synchronisation: profiles/r04_cli.md); everything else as before
+    if (ctx->resident_on && n != 0 && n * 8 <= kSmallCallBytes && ctx->variant == 0) {
+        bool busy = false;
+        for (const dpx_ctx::AsyncSlot &a : ctx->async_slots) busy = busy || a.seq != 0;
+        if (!busy) {
+            dpx_ticket t = 0;
+            uint32_t sn = *samplenum;
+            int rc = dpx_shift_block_async(ctx, in, in_bytes, in_fmt, out_fmt, &sn, shift_hz, samplerate, &t);
+            if (rc == DPX_OK) rc = dpx_wait(ctx, t, out, out_cap, n_samples_out);
+            if (rc == DPX_OK) *samplenum = sn;
+            return rc;
+        }
+    }
     int rc = run_host(ctx, in, n, in_fmt, out, out_fmt, samplenum, shift_hz, samplerate);
     if (rc == DPX_OK && n_samples_out) *n_samples_out = n;
     return rc;
@@ -547,42 +719,71 @@ int dpx_shift_block_async(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_
     const uint32_t seq = ctx->async_next_seq;
     dpx_ctx::AsyncSlot &a = ctx->async_slots[seq % dpx_ctx::kAsyncSlots];
     if (a.seq != 0) return fail(DPX_ERR_PLAN, "%d blocks are in flight: dpx_wait for ticket %u first", dpx_ctx::kAsyncSlots, a.seq);
-    if (!a.host) {
-        void *h = nullptr, *d = nullptr;
-        DPX_HIP(hipHostMalloc(&h, 2 * kSmallCallBytes + kSmallPlanBytes, hipHostMallocMapped));
-        hipError_t e = hipHostGetDevicePointer(&d, h, 0);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&a.done, hipEventDisableTiming);
-        if (e != hipSuccess) {
-            (void)hipHostFree(h);
-            return fail(DPX_ERR_HIP, "asynchronous block slot: %s", hipGetErrorString(e));
-        }
-        a.host = static_cast<char *>(h);
-        a.dev = static_cast<char *>(d);
-    }
+    int rc = alloc_slot(a);
+    if (rc != DPX_OK) return rc;
     dpx::PlanResult plan;
     uint32_t sn = *samplenum;
     dpx::plan_append(plan, dpx::ratio_of(shift_hz, samplerate), n, sn, 1 /* sincos per sample */, &ctx->periods);
     a.n_samples = n;
     a.out_bytes = n * bytes_per_sample(out_fmt);
-    if (n != 0) {
+    a.resident = false;
+    auto issue = [&](uint32_t sn_after) {
+        a.seq = seq;
+        uint32_t next = seq + 1;
+        if (next == 0 || next == dpx::kDoorExit) next = 1;           // 0 marks a free slot, kDoorExit asks the resident kernel to leave
+        ctx->async_next_seq = next;
+        *samplenum = sn_after;            // the counter after the block is known as soon as the block is planned
+        *ticket = seq;
+        return DPX_OK;
+    };
+    if (n == 0) {
+        if (ctx->resident_running) { rc = resident_stop(ctx); if (rc != DPX_OK) return rc; }
+        DPX_HIP(hipEventRecord(a.done, ctx->stream));
+        return issue(sn);
+    }
+    bool tabulated = false;
+    for (const dpx::DevSeg &sg : plan.segs) tabulated = tabulated || sg.lut_len != 0;
+    if (tabulated) {
+        // The block's plan wants a corrector table (periods below 4: shift 0, samplerate / 2 ...; the reference resets the
+        // counter on every sample there): this block takes the synchronous path into the slot's output buffer — same bytes,
+        // same ticket protocol, no overlap for this one block.
+        uint32_t sn_sync = *samplenum;
+        rc = run_host(ctx, in, n, in_fmt, a.host + kSmallOutOff, out_fmt, &sn_sync, shift_hz, samplerate);
+        if (rc != DPX_OK) return rc;
+        DPX_HIP(hipEventRecord(a.done, ctx->stream));
+        return issue(sn_sync);
+    }
+    if (ctx->resident_on && plan.segs.size() <= dpx::kResidentMaxSegs) {
+        // ---- the resident kernel: payload and stretch list into the slot, then the doorbell
+        dpx::BlockCtl *c = slot_ctl(a);
+        memcpy(a.host + kSmallInOff, in, in_bytes);
+        memcpy(a.host + kSmallPlanOff, plan.segs.data(), plan.segs.size() * sizeof(dpx::DevSeg));
+        c->n_samples = (uint32_t)n;
+        c->n_segs = (uint32_t)plan.segs.size();
+        c->legacy = (ctx->i16_cast == DPX_CAST_LEGACY_X86 && out_fmt == DPX_FMT_I16) ? 1u : 0u;
+        rc = resident_ensure(ctx, in_fmt, out_fmt);
+        if (rc == DPX_OK) {
+            store_rel(&c->doorbell, seq);
+            a.resident = true;
+            ++ctx->resident_blocks;
+            return issue(sn);
+        }
+        if (ctx->resident_on) return rc;              // (a kernel that does not answer turns the mode off: the launch path below)
+    }
+    // ---- one launch per block (round 3's path): periods the resident kernel's slot cannot hold, or resident mode off
+    if (ctx->resident_running) { rc = resident_stop(ctx); if (rc != DPX_OK) return rc; }
+    {
         const dpx::LaunchGeom g = geometry(ctx);
         dpx::finalize(plan, g.tile(), dpx::kChooseTileOnly);
         if (plan.error) return fail(DPX_ERR_PLAN, "%s", plan.error);
         const size_t seg_bytes = align256(plan.segs.size() * sizeof(dpx::DevSeg));
         const size_t hint_bytes = plan.hint.size() * sizeof(uint32_t);
         if (plan.lut_entries != 0 || seg_bytes + hint_bytes > kSmallPlanBytes) {
-            // The block's plan wants a corrector table (periods below 4: shift 0, samplerate / 2 ...; the reference resets the
-            // counter on every sample there) or has more stretches than a slot holds: this block takes the synchronous path
-            // into the slot's output buffer — same bytes, same ticket protocol, no overlap for this one block.
             uint32_t sn_sync = *samplenum;
-            const int rc = run_host(ctx, in, n, in_fmt, a.host + kSmallOutOff, out_fmt, &sn_sync, shift_hz, samplerate);
+            rc = run_host(ctx, in, n, in_fmt, a.host + kSmallOutOff, out_fmt, &sn_sync, shift_hz, samplerate);
             if (rc != DPX_OK) return rc;
             DPX_HIP(hipEventRecord(a.done, ctx->stream));
-            a.seq = seq;
-            ctx->async_next_seq = seq + 1 == 0 ? 1 : seq + 1;
-            *samplenum = sn_sync;
-            *ticket = seq;
-            return DPX_OK;
+            return issue(sn_sync);
         }
         memcpy(a.host + kSmallInOff, in, in_bytes);
         memcpy(a.host + kSmallPlanOff, plan.segs.data(), plan.segs.size() * sizeof(dpx::DevSeg));
@@ -591,15 +792,11 @@ int dpx_shift_block_async(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_
         dev.segs = reinterpret_cast<dpx::DevSeg *>(a.dev + kSmallPlanOff);
         dev.hint = reinterpret_cast<uint32_t *>(a.dev + kSmallPlanOff + seg_bytes);
         dev.lut = a.dev + kSmallPlanOff;      // never read: no tabulated stretch in this plan
-        const int rc = run_plan(plan, dev, a.dev + kSmallInOff, in_fmt, a.dev + kSmallOutOff, out_fmt, ctx->fma, g, ctx->stream);
+        rc = run_plan(plan, dev, a.dev + kSmallInOff, in_fmt, a.dev + kSmallOutOff, out_fmt, ctx->fma, g, ctx->stream);
         if (rc != DPX_OK) return rc;
     }
     DPX_HIP(hipEventRecord(a.done, ctx->stream));
-    a.seq = seq;
-    ctx->async_next_seq = seq + 1 == 0 ? 1 : seq + 1;
-    *samplenum = sn;            // the counter after the block is known as soon as the block is planned
-    *ticket = seq;
-    return DPX_OK;
+    return issue(sn);
 }
 
 int dpx_wait(dpx_ctx *ctx, dpx_ticket ticket, void *out, size_t out_cap, size_t *n_samples_out)
@@ -609,14 +806,56 @@ int dpx_wait(dpx_ctx *ctx, dpx_ticket ticket, void *out, size_t out_cap, size_t 
     if (a.seq != ticket) return fail(DPX_ERR_ARG, "ticket %u is not in flight", ticket);
     if (a.out_bytes > out_cap || (!out && a.out_bytes))
         return fail(DPX_ERR_CAPACITY, "output needs %zu bytes, capacity %zu", a.out_bytes, out_cap);
-    const hipError_t e = hipEventSynchronize(a.done);
-    if (e != hipSuccess) {
-        a.seq = 0;                  // the slot is free again whatever happened to its block
-        return fail(DPX_ERR_HIP, "waiting for ticket %u: %s", ticket, hipGetErrorString(e));
+    if (a.resident) {
+        // the block's completion word in host memory; a kernel that left meanwhile (idle clock) is launched again and
+        // finds the doorbell rung
+        dpx::BlockCtl *c = slot_ctl(a);
+        const double t0 = mono_s();
+        uint32_t spins = 0;
+        while (load_acq(&c->done) != ticket) {
+            if ((++spins & 63u) == 0) {
+                if (load_acq(&c->state) == dpx::kResidentParked && load_acq(&c->done) != ticket) {
+                    DPX_HIP(hipSetDevice(ctx->device));
+                    const int rc = resident_ensure(ctx, ctx->resident_in, ctx->resident_out);
+                    if (rc != DPX_OK) { a.seq = 0; return rc; }
+                }
+                if (mono_s() - t0 > kResidentTimeoutS) {
+                    a.seq = 0;
+                    ctx->resident_on = false;
+                    return fail(DPX_ERR_HIP, "the resident block kernel did not finish ticket %u", ticket);
+                }
+            }
+            cpu_relax();
+        }
+    } else {
+        const hipError_t e = hipEventSynchronize(a.done);
+        if (e != hipSuccess) {
+            a.seq = 0;                  // the slot is free again whatever happened to its block
+            return fail(DPX_ERR_HIP, "waiting for ticket %u: %s", ticket, hipGetErrorString(e));
+        }
     }
     if (a.out_bytes) memcpy(out, a.host + kSmallOutOff, a.out_bytes);
     if (n_samples_out) *n_samples_out = a.n_samples;
     a.seq = 0;
+    return DPX_OK;
+}
+
+int dpx_set_resident(dpx_ctx *ctx, int on)
+{
+    if (!ctx) return fail(DPX_ERR_ARG, "ctx is null");
+    if (!on && ctx->resident_running) {
+        const int rc = resident_stop(ctx);
+        if (rc != DPX_OK) return rc;
+    }
+    ctx->resident_on = on != 0;
+    return DPX_OK;
+}
+
+int dpx_resident_stats(const dpx_ctx *ctx, uint64_t *launches, uint64_t *blocks)
+{
+    if (!ctx) return fail(DPX_ERR_ARG, "ctx is null");
+    if (launches) *launches = ctx->resident_launches;
+    if (blocks) *blocks = ctx->resident_blocks;
     return DPX_OK;
 }
 
@@ -664,7 +903,7 @@ int dpx_convert_iqi16_to_complex(dpx_ctx *ctx, const uint8_t *inbuf, size_t in_b
     if (n > out_cap) return fail(DPX_ERR_CAPACITY, "output needs %zu samples, capacity %zu", n, out_cap);
     if (n_out) *n_out = n;
     if (n == 0) return DPX_OK;
-    DPX_HIP(hipSetDevice(ctx->device));
+    DPX_ENTER(ctx);
     int rc = ensure_stage(ctx, in_bytes, n * 8);
     if (rc != DPX_OK) return rc;
     DPX_HIP(hipMemcpyAsync(ctx->stage_in, inbuf, in_bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -693,7 +932,7 @@ int dpx_pack_iqi16(dpx_ctx *ctx, const dpx_complex32 *inbuf, size_t n, uint8_t *
     if (!ctx || (n && (!inbuf || !out))) return fail(DPX_ERR_ARG, "bad argument");
     if (n * 4 > out_cap) return fail(DPX_ERR_CAPACITY, "output needs %zu bytes, capacity %zu", n * 4, out_cap);
     if (n == 0) return DPX_OK;
-    DPX_HIP(hipSetDevice(ctx->device));
+    DPX_ENTER(ctx);
     int rc = ensure_stage(ctx, n * 8, n * 4);
     if (rc != DPX_OK) return rc;
     DPX_HIP(hipMemcpyAsync(ctx->stage_in, inbuf, n * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -708,7 +947,7 @@ int dpx_ccexpf(dpx_ctx *ctx, dpx_complex32 *z, size_t n)
 {
     if (!ctx || (n && !z)) return fail(DPX_ERR_ARG, "bad argument");
     if (n == 0) return DPX_OK;
-    DPX_HIP(hipSetDevice(ctx->device));
+    DPX_ENTER(ctx);
     int rc = ensure_stage(ctx, n * 8, 0);
     if (rc != DPX_OK) return rc;
     DPX_HIP(hipMemcpyAsync(ctx->stage_in, z, n * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -723,7 +962,7 @@ int dpx_ccexpf_imag(dpx_ctx *ctx, dpx_complex32 *z, size_t n)
 {
     if (!ctx || (n && !z)) return fail(DPX_ERR_ARG, "bad argument");
     if (n == 0) return DPX_OK;
-    DPX_HIP(hipSetDevice(ctx->device));
+    DPX_ENTER(ctx);
     int rc = ensure_stage(ctx, n * 8, 0);
     if (rc != DPX_OK) return rc;
     DPX_HIP(hipMemcpyAsync(ctx->stage_in, z, n * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -919,6 +1158,7 @@ int dpx_plan_segments(dpx_ctx *ctx, const dpx_segment *segs, size_t n_segs, uint
     dpx::finalize(p->host, p->geom.tile(), plan_choice(ctx), ctx->tuning);
     hipError_t e = hipSetDevice(ctx->device);
     int rc = e == hipSuccess ? DPX_OK : fail(DPX_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    if (rc == DPX_OK) rc = resident_stop(ctx);
     if (rc == DPX_OK && p->host.error) rc = fail(DPX_ERR_PLAN, "%s", p->host.error);
     if (rc == DPX_OK && p->host.n_samples) {
         rc = materialize(ctx, p->host, p->dev, p->fma, ctx->stream);
@@ -975,6 +1215,10 @@ int dpx_run_device(dpx_plan *plan, const void *d_in, int in_fmt, void *d_out, in
     if (plan->host.n_samples == 0) return DPX_OK;
     if (!d_in || !d_out) return fail(DPX_ERR_ARG, "null device pointer");
     if (((uintptr_t)d_in | (uintptr_t)d_out) & 15u) return fail(DPX_ERR_ARG, "device pointers must be 16-byte aligned");
+    if (plan->ctx->resident_running) {           // (one load otherwise) a resident block kernel would hold up this launch's queue
+        const int rc = resident_stop(plan->ctx);
+        if (rc != DPX_OK) return rc;
+    }
     return run_plan(plan->host, plan->dev, d_in, in_fmt, d_out, out_fmt, plan->fma, plan->geom, hip_stream);
 }
 
@@ -1194,7 +1438,7 @@ int dpx_stream_submit(dpx_stream *s, size_t in_bytes, const dpx_segment *segs, s
     if (total != in_bytes / ibs) return fail(DPX_ERR_PLAN, "segments hold %llu samples, the slab %zu",
                                              (unsigned long long)total, in_bytes / ibs);
     dpx_ctx *ctx = s->ctx;                 // planning state (period cache, tuning): the first context's
-    DPX_HIP(hipSetDevice(b.ctx->device));  // the device work: this slab's GPU
+    DPX_ENTER(b.ctx);                      // the device work: this slab's GPU
     using clk = std::chrono::steady_clock;
     const clk::time_point t0 = clk::now();
     auto us_since = [](clk::time_point t) { return std::chrono::duration<double, std::micro>(clk::now() - t).count(); };
@@ -1311,7 +1555,7 @@ int dpx_debug_copy(dpx_ctx *ctx, const void *d_in, void *d_out, size_t n_bytes, 
 int dpx_malloc(dpx_ctx *ctx, size_t bytes, void **d_ptr)
 {
     if (!ctx || !d_ptr) return fail(DPX_ERR_ARG, "bad argument");
-    DPX_HIP(hipSetDevice(ctx->device));
+    DPX_ENTER(ctx);
     DPX_HIP(hipMalloc(d_ptr, bytes ? bytes : 16));
     return DPX_OK;
 }
@@ -1319,6 +1563,7 @@ int dpx_malloc(dpx_ctx *ctx, size_t bytes, void **d_ptr)
 int dpx_free(dpx_ctx *ctx, void *d_ptr)
 {
     if (!ctx) return fail(DPX_ERR_ARG, "bad argument");
+    DPX_ENTER(ctx);               // hipFree waits for the device: a resident block kernel leaves first
     if (d_ptr) DPX_HIP(hipFree(d_ptr));
     return DPX_OK;
 }
@@ -1326,6 +1571,7 @@ int dpx_free(dpx_ctx *ctx, void *d_ptr)
 int dpx_memcpy_h2d(dpx_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
 {
     if (!ctx) return fail(DPX_ERR_ARG, "bad argument");
+    DPX_ENTER(ctx);
     if (bytes) DPX_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
     return DPX_OK;
 }
@@ -1333,6 +1579,7 @@ int dpx_memcpy_h2d(dpx_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
 int dpx_memcpy_d2h(dpx_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 {
     if (!ctx) return fail(DPX_ERR_ARG, "bad argument");
+    DPX_ENTER(ctx);
     if (bytes) DPX_HIP(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
     return DPX_OK;
 }
@@ -1340,7 +1587,7 @@ int dpx_memcpy_d2h(dpx_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 int dpx_synchronize(dpx_ctx *ctx)
 {
     if (!ctx) return fail(DPX_ERR_ARG, "bad argument");
-    DPX_HIP(hipSetDevice(ctx->device));
+    DPX_ENTER(ctx);
     DPX_HIP(hipDeviceSynchronize());
     return DPX_OK;
 }

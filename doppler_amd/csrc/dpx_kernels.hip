@@ -925,6 +925,121 @@ __global__ __launch_bounds__(WAVES * 64) void span_kernel(const uint8_t *__restr
     }
 }
 
+// ---- resident block kernel (dpx_types.h, BlockCtl): workgroup s serves staging slot s, polling its doorbell in host
+// memory.  Everything it touches but its LDS and the shared idle clock is host-mapped (fine-grained: uncached on the device).
+template <int IN_FMT, int OUT_FMT, bool FMA>
+__global__ __launch_bounds__(kResidentThreads) void resident_block_kernel(ResidentArgs ra)
+{
+    __shared__ DevSeg s_segs[kResidentMaxSegs];
+    __shared__ uint32_t s_door, s_leave, s_n, s_nsegs, s_legacy;
+    const uint32_t tid = threadIdx.x, slot = blockIdx.x;
+    BlockCtl *ctl = ra.ctl[slot];
+    const uint8_t *in = ra.in[slot];
+    uint8_t *out = ra.out[slot];
+    const DevSeg *segs_host = ra.segs[slot];
+    if (tid == 0) {
+        s_door = __hip_atomic_load(&ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&ra.shared->activity, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    uint32_t last = s_door, served = 0, empty = 0;
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) {
+            // doorbell, sample count, stretch count and cast mode are the first 16 bytes of the host-written line: ONE PCIe
+            // read (the host stores the doorbell last, with release semantics; an aligned 16-byte read sees one state of the line)
+            const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(ctl));
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            const uint32_t d = w[0];
+            uint32_t leave = d == kDoorExit ? 1u : 0u;
+            if (d == last) {                                      // (a block that has been rung is always finished first)
+                if (__hip_atomic_load(&ra.shared->leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    leave = 1;
+                } else if ((empty & 15u) == 15u) {
+                    const unsigned long long act = __hip_atomic_load(&ra.shared->activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long now = (unsigned long long)wall_clock64();
+                    if (now > act && now - act > ra.idle_ticks) {
+                        __hip_atomic_store(&ra.shared->leaving, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        leave = 1;
+                    }
+                }
+            }
+            s_door = d;
+            s_leave = leave;
+            s_n = w[1];
+            s_nsegs = w[2];
+            s_legacy = w[3];
+        }
+        __syncthreads();
+        const uint32_t d = s_door, leave = s_leave, n = s_n, n_segs = s_nsegs;
+        const bool legacy = s_legacy != 0;
+        __syncthreads();                                          // the words are rewritten by the next poll
+        if (leave) break;
+        if (d == last) {
+            // nothing new: poll again — at once for the first polls after a block (the next one is usually on its way),
+            // then every few microseconds (each poll is a PCIe read)
+            if (++empty > 4096) __builtin_amdgcn_s_sleep(127);
+            else if (empty > 64) __builtin_amdgcn_s_sleep(16);
+            continue;
+        }
+        empty = 0;
+        // Everything the block needs comes over PCIe; all of it is requested at once (one round trip, not three): the
+        // stretch list, and every thread's first quad — the reference's block is 2048 (i16) or 1024 (f32) samples: one quad
+        // per thread of the 512; a quad past the block's end reads slot memory that is there and is not used.
+        u32x4 seg_piece = {0, 0, 0, 0};
+        if (tid < kResidentMaxSegs * (uint32_t)(sizeof(DevSeg) / 16)) seg_piece = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(segs_host) + tid);
+        const Quad<IN_FMT> pre = load_quad<IN_FMT>(in, (uint64_t)tid * 4u);
+        if (tid < kResidentMaxSegs * (uint32_t)(sizeof(DevSeg) / 16)) reinterpret_cast<u32x4 *>(s_segs)[tid] = seg_piece;
+        __syncthreads();
+        // four consecutive samples per thread where they lie inside one stretch without a wrap; sample by sample elsewhere
+        const uint32_t nq = n >> 2;
+        uint32_t turn = 0;
+        for (uint32_t q = tid; q < nq + 1; q += kResidentThreads, ++turn) {
+            const uint64_t g = (uint64_t)q * 4u;
+            if (q == nq) {                                        // the last n mod 4 samples
+                for (uint64_t gg = g; gg < n; ++gg) one_sample<IN_FMT, OUT_FMT, FMA>(in, out, s_segs, n_segs, 0, gg, legacy);
+                break;
+            }
+            uint32_t si = 0;
+            while (si + 1 < n_segs && s_segs[si].first + s_segs[si].count <= g) ++si;
+            const DevSeg &sg = s_segs[si];
+            const uint32_t P = sg.period;
+            const uint64_t j = g - sg.first;
+            const uint32_t base = P != 0 ? (uint32_t)(((uint64_t)(sg.n_start - 1u) + j) % P) : sg.n_start + (uint32_t)j;
+            const bool together = g + 4 <= sg.first + sg.count && (P == 0 ? base < 0xfffffffcu : (P >= 4 && base + 4 <= P));
+            if (!together) {
+                for (uint64_t gg = g; gg < g + 4; ++gg) one_sample<IN_FMT, OUT_FMT, FMA>(in, out, s_segs, n_segs, si, gg, legacy);
+                continue;
+            }
+            const uint32_t n0 = P == 0 ? base : base + 1u;
+            const uint32_t cn[4] = {n0, n0 + 1u, n0 + 2u, n0 + 3u};
+            f32x2 cs[4];
+            corrector4<FMA>(sg.ratio, cn, cs);
+            const Quad<IN_FMT> qi = turn == 0 ? pre : load_quad<IN_FMT>(in, g);
+            Quad<OUT_FMT> qo;
+            float re[4], im[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a, b;
+                quad_get<IN_FMT, kRawI16<IN_FMT, OUT_FMT>>(qi, k, a, b);
+                mix(a, b, cs[k].x, cs[k].y, re[k], im[k]);
+            }
+            quad_set4<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(qo, re, im, legacy);
+            store_quad<OUT_FMT>(out, g, qo);
+        }
+        __threadfence_system();                                   // the block's output before its completion word
+        __syncthreads();
+        last = d;
+        ++served;
+        if (tid == 0) {
+            ctl->blocks = served;
+            __hip_atomic_store(&ctl->done, d, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&ra.shared->activity, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (tid == 0) __hip_atomic_store(&ctl->state, kResidentParked, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // plan-time: entry e of a table = corrector(((n_first - 1 + e) mod period) + 1)
 template <bool FMA>
 __global__ __launch_bounds__(256) void build_lut_kernel(float2 *__restrict__ tab, uint32_t period,
@@ -1113,6 +1228,20 @@ int launch_span(const void *d_in, int in_fmt, void *d_out, int out_fmt, const De
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     DPX_DISPATCH_FMT(span_t, d_in, d_out, d_segs, d_walk_desc, d_left, d_left_hint, w, fma, legacy_cast, st);
+}
+
+template <int IN_FMT, int OUT_FMT>
+static int resident_t(const ResidentArgs &args, bool fma, hipStream_t st)
+{
+    if (fma) resident_block_kernel<IN_FMT, OUT_FMT, true><<<kResidentSlots, kResidentThreads, 0, st>>>(args);
+    else     resident_block_kernel<IN_FMT, OUT_FMT, false><<<kResidentSlots, kResidentThreads, 0, st>>>(args);
+    return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;
+}
+
+int launch_resident_block(const ResidentArgs &args, int in_fmt, int out_fmt, bool fma, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DPX_DISPATCH_FMT(resident_t, args, fma, st);
 }
 
 int launch_build_lut(void *d_lut_entries, uint32_t period, uint32_t n_first, uint32_t n_entries,

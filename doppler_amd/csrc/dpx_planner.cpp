@@ -384,7 +384,7 @@ uint64_t walk_row_length_target(uint64_t P, uint64_t target, uint64_t len)
 {
     const uint64_t r = len / P;
     uint64_t m = 1;
-    if (r > 12) m = std::min((target + P - 1) / P, (r + 7) / 8);
+    if (r > 12) m = std::min((target + P - 1) / P, (r + 7) / 8);     // (rows of two periods from 9 rows on: measured equal, profiles/r04_walk.md)
     if (P * m < kWalkMinL) m = (kWalkMinL + P - 1) / P;
     return P * m;
 }

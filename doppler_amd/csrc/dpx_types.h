@@ -195,6 +195,50 @@ struct TileArgs {
     uint32_t pad;
 };
 
+// ---- resident block kernel (round 4): one 8 KiB block per call without a launch per call.
+// The reference's loop hands ONE block at a time to its operator (src/main.rs:113-118).  A launch and an event per block
+// cost 8.6-15.8 us; the kernel below is launched ONCE for a context's staging slots and stays: workgroup s polls the
+// doorbell of slot s in host-mapped memory, and when the host rings it reads the block (samples + stretch list) over PCIe,
+// evaluates it with the per-sample path and writes result and completion word back to host memory.  A block then costs
+// PCIe round trips, not a launch, and the slots' round trips overlap.  The kernel is ONE unit on ONE HIP stream (a
+// resident kernel holds its hardware queue; launches of other streams that share the queue wait for it): all its workgroups
+// leave together — on request (kDoorExit in every doorbell: the context does that before any launch of its own), or once
+// none of them has had work for `idle_ticks` of the 100 MHz wall clock (a word in device memory the first idle workgroup
+// sets), so an abandoned or crashed caller leaves nothing running.  The next block after that pays one launch.
+constexpr int kResidentSlots = 4;
+constexpr int kResidentThreads = 512;      // one quad per thread for the reference's 2048-sample block
+struct BlockCtl {
+    // ---- written by the host, read by the kernel (one 64-byte line)
+    uint32_t doorbell;     // ticket of the block to process; the kernel acts when it differs from `done`; kDoorExit: leave
+    uint32_t n_samples;
+    uint32_t n_segs;       // stretches of this block (DevSeg list in the slot's plan area), at most kResidentMaxSegs
+    uint32_t legacy;       // dpx_set_i16_cast
+    uint32_t pad0[12];
+    // ---- written by the kernel, read by the host (another line)
+    uint32_t done;         // ticket of the last block finished
+    uint32_t state;        // kResidentRunning while the workgroup polls; kResidentParked once it has left (its last store)
+    uint32_t blocks;       // blocks processed since launch (statistics)
+    uint32_t pad1[13];
+};
+static_assert(sizeof(BlockCtl) == 128, "two lines: host-written and kernel-written");
+struct ResidentShared {    // device memory, one per context
+    unsigned long long activity;   // wall clock of the last block any workgroup finished
+    uint32_t leaving;              // set by the first workgroup that finds the kernel idle: everyone leaves
+    uint32_t pad;
+};
+struct ResidentArgs {
+    BlockCtl *ctl[kResidentSlots];
+    const uint8_t *in[kResidentSlots];
+    uint8_t *out[kResidentSlots];
+    const DevSeg *segs[kResidentSlots];
+    ResidentShared *shared;
+    uint64_t idle_ticks;
+};
+constexpr uint32_t kDoorExit = 0xffffffffu;
+constexpr uint32_t kResidentRunning = 1, kResidentParked = 2;
+constexpr uint32_t kResidentMaxSegs = 16;
+int launch_resident_block(const ResidentArgs &args, int in_fmt, int out_fmt, bool fma, void *stream);
+
 // launch wrappers implemented in dpx_kernels.hip (all asynchronous on `stream`)
 int launch_tiles(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,
                  uint32_t n_segs, const uint32_t *d_hint, const void *d_lut, const TileArgs &t,

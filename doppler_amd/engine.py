@@ -76,6 +76,16 @@ class Context:
         walk_span, walk_flags, walk_tilemin); no arguments restores the defaults. Applies to plans created afterwards."""
         check(self._lib.dpx_set_options(self._h, _lib.make_options(opts)))
 
+    def set_resident(self, on=True):
+        """The resident block kernel behind shift_block / shift_block_async (default on); off: a launch per block."""
+        check(self._lib.dpx_set_resident(self._h, 1 if on else 0))
+
+    def resident_stats(self):
+        """(kernel launches, blocks served through doorbells) of the resident block kernel so far."""
+        a, b = C.c_uint64(), C.c_uint64()
+        check(self._lib.dpx_resident_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_libm_contraction(self, fma=True):
         check(self._lib.dpx_set_libm_contraction(self._h, 1 if fma else 0))
 

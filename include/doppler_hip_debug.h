@@ -7,7 +7,7 @@
  *   dpx_plan_describe / _layout / _simulate          the planner's stretch list, launch layout and a host mirror of the
  *                                                    kernels' index arithmetic (tests/test_host_logic.py, no device needed);
  *   dpx_debug_copy                                   the memory system's own copy rate (calibration of profiles/);
- *   dpx_stream_get_stats / _pending, dpx_plan_n_samples   introspection;
+ *   dpx_stream_get_stats / _pending, dpx_plan_n_samples, dpx_set_resident / dpx_resident_stats   introspection, A/B;
  *   dpx_malloc ... dpx_synchronize                   device memory for callers without a HIP binding (ctypes tests, the CLI).
  */
 #ifndef DOPPLER_HIP_DEBUG_H
@@ -83,6 +83,12 @@ int dpx_plan_layout(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
                     int block, int vecs, int variant, const struct dpx_options *opt, dpx_layout *out);
 
 int dpx_plan_n_samples(const dpx_plan *plan, uint64_t *n_samples);
+
+/* The resident block kernel behind dpx_shift_block / dpx_shift_block_async (on by default; DPX_RESIDENT=0 in the environment
+ * turns it off for every context): on = 0 sends every block through a launch of its own again (round 3's path, kept as the
+ * fallback), for A/B timing.  dpx_resident_stats: kernel launches and blocks served through doorbells so far. */
+int dpx_set_resident(dpx_ctx *ctx, int on);
+int dpx_resident_stats(const dpx_ctx *ctx, uint64_t *launches, uint64_t *blocks);
 
 int dpx_stream_pending(const dpx_stream *s, int *n_in_flight);
 /* Host time dpx_stream_submit has spent so far, by part (microseconds, summed over `slabs` calls): planning (stretch list +

@@ -364,4 +364,6 @@ def test_every_wavefront_of_a_workgroup_reaches_its_barrier(tmp_path):
     multi = {k: v for k, v in span.items() if k not in uni}
     assert len(uni) == 24 and len(multi) == 32, (len(uni), len(multi))      # 4 format pairs x 2 libm builds x 3 / 4 workgroup sizes
     assert all(v == 1 for v in span.values()), {k: v for k, v in span.items() if v != 1}
-    assert all(v == 0 for k, v in kern.items() if k not in span), {k[:60]: v for k, v in kern.items() if v and k not in span}
+    resident = {k: v for k, v in kern.items() if "resident_block_kernel" in k}     # polls a doorbell: barriers around its shared words, all uniform
+    assert len(resident) == 8
+    assert all(v == 0 for k, v in kern.items() if k not in span and k not in resident), {k[:60]: v for k, v in kern.items() if v and k not in span and k not in resident}

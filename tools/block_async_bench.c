@@ -1,5 +1,6 @@
 /* block_async_bench — the reference's 8 KiB block through the C ABI: dpx_shift_block (one call, one wait) against
- * dpx_shift_block_async / dpx_wait with 2 and 4 blocks in flight, and dpx_shift_blocks with 64 blocks per call.
+ * dpx_shift_block_async / dpx_wait with 1, 2 and 4 blocks in flight, and dpx_shift_blocks with 64 blocks per call; each with the
+ * resident block kernel (a doorbell per block: the default) and without it (a launch per block: round 3's path).
  *   gcc -O2 -Iinclude tools/block_async_bench.c -Ldoppler_amd/lib -ldoppler_hip -Wl,-rpath,$PWD/doppler_amd/lib -o tools/bin/block_async_bench */
 #include <stdint.h>
 #include <stdio.h>
@@ -8,6 +9,7 @@
 #include <time.h>
 
 #include "doppler_hip.h"
+#include "doppler_hip_debug.h"
 
 static double now(void)
 {
@@ -26,13 +28,18 @@ int main(void)
     for (int i = 0; i < BLK / 2; ++i) in[i] = (int16_t)((i * 7919) % 20000 - 10000);
     uint32_t sn = 0;
     size_t n;
+    double t, dt;
+    for (int resident = 1; resident >= 0; --resident) {
+    dpx_set_resident(ctx, resident);
+    printf("== %s\n", resident ? "resident block kernel (doorbell per block)" : "a launch per block (DPX_RESIDENT=0)");
+    sn = 0;
     for (int i = 0; i < 200; ++i) dpx_shift_block(ctx, in, BLK, DPX_FMT_I16, out[0], BLK, DPX_FMT_I16, &sn, 5000.0f, 1024000, &n);
-    double t = now();
+    t = now();
     for (int i = 0; i < NB; ++i) dpx_shift_block(ctx, in, BLK, DPX_FMT_I16, out[0], BLK, DPX_FMT_I16, &sn, 5000.0f, 1024000, &n);
-    double dt = now() - t;
+    dt = now() - t;
     printf("dpx_shift_block, 8 KiB per call:           %6.2f us per block = %7.1f Msamples/s\n", dt / NB * 1e6, NB * 2048.0 / dt / 1e6);
     const uint32_t sn_sync = sn;
-    for (int depth = 2; depth <= 4; depth += 2) {
+    for (int depth = 1; depth <= 4; depth *= 2) {
         sn = 0;
         for (int i = 0; i < 200; ++i) dpx_shift_block(ctx, in, BLK, DPX_FMT_I16, out[0], BLK, DPX_FMT_I16, &sn, 5000.0f, 1024000, &n);
         dpx_ticket tk[4];
@@ -54,6 +61,10 @@ int main(void)
         dt = now() - t;
         printf("dpx_shift_block_async, %d blocks in flight: %6.2f us per block = %7.1f Msamples/s  (counter %s)\n", depth, dt / NB * 1e6,
                NB * 2048.0 / dt / 1e6, sn == sn_sync ? "as the synchronous loop's" : "DIFFERS");
+    }
+    uint64_t launches = 0, blocks = 0;
+    dpx_resident_stats(ctx, &launches, &blocks);
+    printf("resident kernel so far: %llu launches, %llu blocks through doorbells\n", (unsigned long long)launches, (unsigned long long)blocks);
     }
     {
         enum { K = 64 };
