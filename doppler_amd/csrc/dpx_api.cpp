@@ -16,7 +16,13 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/doppler_hip.h"
@@ -1273,6 +1279,14 @@ struct dpx_stream_slab {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     int numa_node = -1;          // where the pinned buffers were placed (-1: the caller's default policy)
+    // several GPUs: the device work of a slab is enqueued by its GPU's own thread (dpx_stream::Worker)
+    std::atomic<int> enq{0};     // 0: nothing pending; 1: handed to the worker; 2: enqueued (enq_rc says how it went)
+    int enq_rc = 0;
+    std::string enq_err;
+    size_t job_in_bytes = 0;
+    bool job_reuse = false;
+    dpx::LaunchGeom job_geom = {128, 2};
+    bool job_fma = true;
     dpx::PlanResult plan;
     DevPlan dev;
     size_t out_bytes = 0;
@@ -1294,7 +1308,25 @@ struct dpx_stream {
     size_t rel = 0;     // oldest handed-out slab                     (release, in the same order)
     std::atomic<int> in_flight{0};
     dpx_stream_stats stats = {};   // host cost of dpx_stream_submit, by part (dpx_stream_get_stats)
+    // Several GPUs: one enqueue thread per context.  dpx_stream_submit plans on the caller's thread (the counter is carried
+    // from slab to slab: sequential by nature, 0.1-1 us) and hands the device work — plan image, H2D, launch, D2H, event:
+    // 7-12 us of HIP calls — to the thread of the slab's GPU, so that eight GPUs are fed by eight threads, each running on
+    // the NUMA node of its GPU, and a slow call into one GPU's runtime does not hold up the others.
+    struct Worker {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<size_t> jobs;
+        bool stop = false;
+    };
+    std::vector<std::unique_ptr<Worker>> workers;
+    std::mutex enq_mu;             // guards stats' upload / enqueue parts and wakes dpx_stream_next
+    std::condition_variable enq_cv;
 };
+
+namespace {
+void slab_worker(dpx_stream *s, dpx_stream::Worker *w, int numa_node);
+}
 
 namespace {
 
@@ -1384,6 +1416,13 @@ int dpx_stream_create_multi(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out
             return fail(DPX_ERR_HIP, "stream slab allocation failed: %s", hipGetErrorString(e));
         }
     }
+    if (n_ctx > 1) {
+        for (int i = 0; i < n_ctx; ++i) {
+            s->workers.emplace_back(new dpx_stream::Worker);
+            dpx_stream::Worker *w = s->workers.back().get();
+            w->th = std::thread(slab_worker, s, w, s->slabs[(size_t)i].numa_node);
+        }
+    }
     *out = s;
     return DPX_OK;
 }
@@ -1398,6 +1437,11 @@ int dpx_stream_create(dpx_ctx *ctx, int in_fmt, int out_fmt, uint32_t samplerate
 void dpx_stream_destroy(dpx_stream *s)
 {
     if (!s) return;
+    for (auto &w : s->workers) {                     // the enqueue threads finish what they were handed, then leave
+        { std::lock_guard<std::mutex> lk(w->mu); w->stop = true; }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+    }
     for (dpx_stream_slab &b : s->slabs) {
         if (b.ctx) (void)hipSetDevice(b.ctx->device);
         if (b.stream) (void)hipStreamSynchronize(b.stream);
@@ -1424,6 +1468,81 @@ int dpx_stream_acquire(dpx_stream *s, void **pinned_in, size_t *capacity_bytes)
     return DPX_OK;
 }
 
+namespace {
+
+// the device work of one submitted slab: plan image (unless the slab's resident one is reused), H2D, launch, D2H, event
+int enqueue_slab(dpx_stream *s, dpx_stream_slab &b, double *upload_us, double *enqueue_us)
+{
+    using clk = std::chrono::steady_clock;
+    auto us_since = [](clk::time_point t) { return std::chrono::duration<double, std::micro>(clk::now() - t).count(); };
+    DPX_ENTER(b.ctx);
+    const clk::time_point t1 = clk::now();
+    if (b.out_bytes == 0) {
+        DPX_HIP(hipEventRecord(b.done, b.stream));
+        return DPX_OK;
+    }
+    int rc;
+    if (!b.job_reuse) {
+        rc = materialize(b.ctx, b.plan, b.dev, b.job_fma, b.stream);
+        if (rc != DPX_OK) return rc;
+    }
+    const clk::time_point t2 = clk::now();
+    *upload_us += us_since(t1);
+    DPX_HIP(hipMemcpyAsync(b.d_in, b.h_in, b.job_in_bytes, hipMemcpyHostToDevice, b.stream));
+    rc = run_plan(b.plan, b.dev, b.d_in, s->in_fmt, b.d_out, s->out_fmt, b.job_fma, b.job_geom, b.stream);
+    if (rc != DPX_OK) return rc;
+    DPX_HIP(hipMemcpyAsync(b.h_out, b.d_out, b.out_bytes, hipMemcpyDeviceToHost, b.stream));
+    DPX_HIP(hipEventRecord(b.done, b.stream));
+    *enqueue_us += us_since(t2);
+    return DPX_OK;
+}
+
+void slab_worker(dpx_stream *s, dpx_stream::Worker *w, int numa_node)
+{
+    // run where the GPU's pinned slabs live (sched_setaffinity to the node's CPUs: sysfs cpulist; silent on failure)
+    if (numa_node >= 0) {
+        char path[96];
+        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", numa_node);
+        if (FILE *f = fopen(path, "r")) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            int a = 0, b2 = 0, n = 0;
+            char sep = 0;
+            while (fscanf(f, "%d", &a) == 1) {
+                b2 = a;
+                if (fscanf(f, "%c", &sep) == 1 && sep == '-') { if (fscanf(f, "%d", &b2) != 1) b2 = a; if (fscanf(f, "%c", &sep) != 1) sep = 0; }
+                for (int c = a; c <= b2 && c < CPU_SETSIZE; ++c) { CPU_SET(c, &set); ++n; }
+                if (sep != ',') break;
+            }
+            fclose(f);
+            if (n > 0) (void)sched_setaffinity(0, sizeof set, &set);
+        }
+    }
+    for (;;) {
+        size_t k;
+        {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return w->stop || !w->jobs.empty(); });
+            if (w->jobs.empty()) return;
+            k = w->jobs.front();
+            w->jobs.pop_front();
+        }
+        dpx_stream_slab &b = s->slabs[k];
+        double up = 0, en = 0;
+        b.enq_rc = enqueue_slab(s, b, &up, &en);
+        if (b.enq_rc != DPX_OK) b.enq_err = dpx_last_error();
+        {
+            std::lock_guard<std::mutex> lk(s->enq_mu);
+            s->stats.upload_us += up;
+            s->stats.enqueue_us += en;
+            b.enq.store(2, std::memory_order_release);
+        }
+        s->enq_cv.notify_all();
+    }
+}
+
+}  // namespace
+
 int dpx_stream_submit(dpx_stream *s, size_t in_bytes, const dpx_segment *segs, size_t n_segs)
 {
     if (!s || (n_segs && !segs)) return fail(DPX_ERR_ARG, "bad argument");
@@ -1438,7 +1557,6 @@ int dpx_stream_submit(dpx_stream *s, size_t in_bytes, const dpx_segment *segs, s
     if (total != in_bytes / ibs) return fail(DPX_ERR_PLAN, "segments hold %llu samples, the slab %zu",
                                              (unsigned long long)total, in_bytes / ibs);
     dpx_ctx *ctx = s->ctx;                 // planning state (period cache, tuning): the first context's
-    DPX_ENTER(b.ctx);                      // the device work: this slab's GPU
     using clk = std::chrono::steady_clock;
     const clk::time_point t0 = clk::now();
     auto us_since = [](clk::time_point t) { return std::chrono::duration<double, std::micro>(clk::now() - t).count(); };
@@ -1462,31 +1580,34 @@ int dpx_stream_submit(dpx_stream *s, size_t in_bytes, const dpx_segment *segs, s
         dpx::finalize(b.plan, g.tile(), plan_choice(ctx), ctx->tuning);
         if (b.plan.error) return fail(DPX_ERR_PLAN, "%s", b.plan.error);
     }
-    const clk::time_point t1 = clk::now();
     s->stats.plan_us += us_since(t0);
     b.out_bytes = (size_t)total * obs;
-    if (total) {
-        int rc;
-        if (!reuse) {
-            rc = materialize(b.ctx, b.plan, b.dev, ctx->fma, b.stream);
-            if (rc != DPX_OK) return rc;
-        }
-        const clk::time_point t2 = clk::now();
-        s->stats.upload_us += us_since(t1);
-        DPX_HIP(hipMemcpyAsync(b.d_in, b.h_in, in_bytes, hipMemcpyHostToDevice, b.stream));
-        rc = run_plan(b.plan, b.dev, b.d_in, s->in_fmt, b.d_out, s->out_fmt, ctx->fma, g, b.stream);
-        if (rc != DPX_OK) return rc;
-        DPX_HIP(hipMemcpyAsync(b.h_out, b.d_out, b.out_bytes, hipMemcpyDeviceToHost, b.stream));
-        DPX_HIP(hipEventRecord(b.done, b.stream));
-        s->stats.enqueue_us += us_since(t2);
-        if (!reuse) {
-            b.key = key;
-            b.key_segs.assign(segs, segs + n_segs);
-            b.key_sn_after = sn;
-            b.have_key = true;
-        }
+    b.job_in_bytes = in_bytes;
+    b.job_reuse = reuse;
+    b.job_geom = g;
+    b.job_fma = ctx->fma;
+    if (total && !reuse) {                  // (the key describes the plan; a failed enqueue is reported by dpx_stream_next)
+        b.key = key;
+        b.key_segs.assign(segs, segs + n_segs);
+        b.key_sn_after = sn;
+        b.have_key = true;
+    }
+    if (s->workers.empty()) {
+        double up = 0, en = 0;
+        const int rc = enqueue_slab(s, b, &up, &en);
+        if (rc != DPX_OK) { b.have_key = false; return rc; }
+        s->stats.upload_us += up;
+        s->stats.enqueue_us += en;
+        b.enq.store(0, std::memory_order_relaxed);
     } else {
-        DPX_HIP(hipEventRecord(b.done, b.stream));
+        // the device work goes to the thread of this slab's GPU; dpx_stream_next waits for it, then for the event
+        dpx_stream::Worker &w = *s->workers[s->head % s->workers.size()];
+        b.enq.store(1, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(w.mu);
+            w.jobs.push_back(s->head);
+        }
+        w.cv.notify_one();
     }
     ++s->stats.slabs;
     s->stats.total_us += us_since(t0);
@@ -1509,6 +1630,21 @@ int dpx_stream_next(dpx_stream *s, const void **pinned_out, size_t *out_bytes)
     if (!s || !pinned_out || !out_bytes) return fail(DPX_ERR_ARG, "bad argument");
     dpx_stream_slab &b = s->slabs[s->tail];
     if (b.state != 2) return fail(DPX_ERR_PLAN, "nothing in flight");
+    if (b.enq.load(std::memory_order_acquire) != 0) {          // several GPUs: the slab's enqueue thread first
+        std::unique_lock<std::mutex> lk(s->enq_mu);
+        s->enq_cv.wait(lk, [&] { return b.enq.load(std::memory_order_acquire) == 2; });
+        lk.unlock();
+        b.enq.store(0, std::memory_order_relaxed);
+        if (b.enq_rc != DPX_OK) {
+            b.have_key = false;
+            b.state = 3;                                       // the slab is handed out (empty) so that the ring keeps turning
+            s->tail = (s->tail + 1) % s->slabs.size();
+            *pinned_out = b.h_out;
+            *out_bytes = 0;
+            return fail(b.enq_rc, "%s", b.enq_err.c_str());
+        }
+        DPX_HIP(hipSetDevice(b.ctx->device));
+    }
     DPX_HIP(hipEventSynchronize(b.done));
     b.state = 3;
     s->tail = (s->tail + 1) % s->slabs.size();

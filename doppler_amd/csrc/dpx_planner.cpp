@@ -457,16 +457,19 @@ uint64_t walk_workgroups(const WalkSeg &w, const PlanTuning &tn)
 
 // What one launch makes of a plan's span shape for its format pair (dpx_types.h, SpanLaunch).
 //
-// One matrix (const mode).  Its spans follow from the kernel arguments, so the LAUNCH may cut them differently per pair.
-// Every pair with an f32 side wants half the rows per workgroup, each under its own number of wavefronts (the ones
-// without rows still share the slice) — spans of 4 against the plan's spans of 8, four shifts, two processes each
-// (`tools/ab.py --set pairs3 / pairs4`, profiles/r03_walk.md):
-//   f32 -> f32, 4 wavefronts: 82-83 % against 75-77;   f32 -> i16, 5 wavefronts: 80-83.7 against 75-77;
-//   i16 -> f32, 2 wavefronts: 77-78.6 against 74-76 (68 under 4);   i16 -> i16 keeps 4 x 8 (spans of 4: 57-72).
-// Not when the caller fixed a shape (auto_shape == 0).
+// One matrix (const mode).  Its spans follow from the kernel arguments, so the LAUNCH may cut them per pair — and the rule
+// is about the memory side, not about arithmetic (profiles/r04_pairs_pmc.md: request mix, vector-ALU load and LDS are the same
+// for every shape; what differs is how long requests queue at the L2's memory port): a workgroup should keep about 8 KiB
+// of its column window in flight per direction.  A row vector (256 samples) is 1 KiB of i16 or 2 KiB of f32, so a span is
+//     8 KiB / (the wider side's row vector)  =  8 rows for i16 -> i16,  4 rows for every pair with an f32 side
+// (f32 -> f32: DRAM credit stalls per request 0.32 -> 0.06, requests in flight 3788 -> 3306 at 83 % instead of 78 %;
+// i16 -> i16 with spans of 4 only doubles the slice arithmetic: 75.8 % against 79.6).  With so few rows the wavefronts are
+// there for the slice: 4 for f32 -> f32 (half windows: 160 entries), 5 for f32 -> i16 (whole windows of 288 entries and the
+// LDS transposition), 2 for i16 -> f32 (half windows, 8-byte loads: 79.4 % against 69.9 under 4).  Measured on four shifts,
+// two processes each, in round 3 (`tools/ab.py --set pairs3 / pairs4`).  Not when the caller fixed a shape (auto_shape == 0).
 // Many matrices (track mode).  The descriptors fix the spans, not the workgroup size: f32 -> i16 (two 16-byte loads per
-// lane per row) ran its replays 1.5-2 points faster under 8 wavefronts on two boxes (77.2 -> 78.8, 76.6 -> 78.9 %); the
-// other pairs lose under more than 4 (i16 -> f32 73.8 -> 61.4).  The planner's window shifts divide 4, hence 8.
+// lane per row) runs its replays 1.5-2 points faster under 8 wavefronts (78.4 against 76.4 %, this round); the other pairs
+// lose under more than 4 (i16 -> f32 74.6 -> 72.6).  The planner's window shifts divide 4, hence 8.
 bool span_launch_shape(const WalkArgs &w, int in_fmt, int out_fmt, SpanLaunch *o)
 {
     const bool in_f32 = in_fmt == 1, out_f32 = out_fmt == 1;
@@ -474,8 +477,11 @@ bool span_launch_shape(const WalkArgs &w, int in_fmt, int out_fmt, SpanLaunch *o
     o->waves = w.waves;
     const bool uni = w.uni.n_spans != 0;
     o->left_rows = uni ? (w.n_left_wg + w.uni.nw8 - 1) / w.uni.nw8 : 0;
-    if (uni && w.auto_shape && (in_f32 || out_f32) && w.uni.seg.rows > kSpanWhole) {
-        const uint32_t k = (w.uni.seg.rows + 3) / 4;
+    constexpr uint32_t kWindowBytesInFlight = 8192;
+    const uint32_t row_vector = kWalkWindow * std::max(in_f32 ? 8u : 4u, out_f32 ? 8u : 4u);
+    const uint32_t span_rows = kWindowBytesInFlight / row_vector;                 // 8 or 4
+    if (uni && w.auto_shape && span_rows < kSpanRows && w.uni.seg.rows > kSpanWhole) {
+        const uint32_t k = (w.uni.seg.rows + span_rows - 1) / span_rows;
         if ((uint64_t)k + o->left_rows <= 65535u) {
             o->uni.n_spans = k;
             o->uni.base = w.uni.seg.rows / k;
