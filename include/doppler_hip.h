@@ -101,27 +101,30 @@ int dpx_pack_iqi16(dpx_ctx *ctx, const dpx_complex32 *inbuf, size_t n, uint8_t *
 
 /* The whole body of the `shift` closure (main.rs:65-94) fused into one kernel:
  * unpack -> mix -> pack, never materialising Complex<f32> in memory.  Any number
- * of bytes (not limited to 8192); `samplenum` in/out as above. */
+ * of bytes (not limited to 8192); `samplenum` in/out as above.  Per 8 KiB call: 12.7 us (see dpx_shift_block_async). */
 int dpx_shift_block(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt,
                     void *out, size_t out_cap, int out_fmt, uint32_t *samplenum,
                     float shift_hz, uint32_t samplerate, size_t *n_samples_out);
 
-/* Many blocks per call: what a caller that wants the GPU's rate rather than 20 us per 8 KiB does with the loop of
+/* Many blocks per call: what a caller that wants the GPU's rate rather than a block per call does with the loop of
  * main.rs:113-118 / 160-183 — read up to N blocks, one call.  in_bytes may end with a short block (the reference's last
  * read); shift_hz[b] is the shift of block b (8192 input bytes each, the granularity at which the reference can change
  * it), n_blocks = ceil(in_bytes / 8192).  The counter is carried through all blocks exactly as through N calls of
- * dpx_shift_block.  Measured per call (pageable host memory): 8 KiB 20 us, 64 KiB 52 us, 1 MiB 133 us, 16 MiB 676 us. */
+ * dpx_shift_block.  Measured per call (pageable host memory): 64 KiB 52 us, 1 MiB 133 us, 16 MiB 676 us. */
 int dpx_shift_blocks(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt, void *out, size_t out_cap, int out_fmt,
                      uint32_t *samplenum, const float *shift_hz, size_t n_blocks, uint32_t samplerate, size_t *n_samples_out);
 
 /* The same block, asynchronously: dpx_shift_block_async copies the block into one of four pinned, device-mapped staging
  * buffers, enqueues the fused kernel and returns at once with a ticket; `samplenum` is already the counter after the block
- * (it follows from the closed form, not from the kernel).  dpx_wait blocks until that block is done and copies its output
+ * (it follows from the closed form, not from the kernel).  dpx_wait waits until that block is done and copies its output
  * out.  So the loop of main.rs:113-118 can read block k + 1 from stdin while block k is on the GPU:
  *     dpx_shift_block_async(ctx, blk[k+1], ...&t[k+1]);  dpx_wait(ctx, t[k], out, ...);  write(out);
  * Tickets complete in the order they were issued; at most four may be outstanding (DPX_ERR_PLAN beyond that).  Blocks of
- * up to 8192 samples (the reference's block is 2048 / 1024).  Measured per 8 KiB block: 19.7 us synchronous, see
- * profiles/r03_cli.md for the overlapped figure. */
+ * up to 8192 samples (the reference's block is 2048 / 1024); every input dpx_shift_block takes is taken.
+ * Round 4: the blocks of both calls go to a RESIDENT kernel (one workgroup per staging buffer polling a doorbell in the
+ * buffer; it leaves when idle for 2 ms or when the context launches anything else), so a block costs PCIe round trips,
+ * not a launch: 12.7 us per 8 KiB block alone, 3.2 us with four in flight (a launch per block: 17.9 / 10.0 us;
+ * profiles/r04_cli.md).  DPX_RESIDENT=0 in the environment restores a launch per block. */
 typedef uint32_t dpx_ticket;
 int dpx_shift_block_async(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt, int out_fmt, uint32_t *samplenum,
                           float shift_hz, uint32_t samplerate, dpx_ticket *ticket);
@@ -202,8 +205,8 @@ int dpx_set_libm_contraction(dpx_ctx *ctx, int fma);
  *       code a 2016 rustc (the toolchain of the reference's Cargo.lock) emitted for the then-undefined out-of-range case
  *       (`fptosi float to i16` = CVTTSS2SI into a 32-bit register, low half stored).  For byte-for-byte comparisons with
  *       output files produced by binaries of that time.
- * Applies to plans created afterwards and to the host-pointer operators; plans of the legacy mode run on the tile kernel
- * only (70-85 % of the default plans' rate).  f32 output is not affected. */
+ * Applies to plans created afterwards and to the host-pointer operators; the mode is a launch-uniform flag of every kernel
+ * (the same plans and rates as the default).  f32 output is not affected. */
 #define DPX_CAST_SATURATE 0
 #define DPX_CAST_LEGACY_X86 1
 int dpx_set_i16_cast(dpx_ctx *ctx, int mode);

@@ -2,12 +2,12 @@
 # Runs on the GPU box (through gpurun): rocprofv3 kernel-trace stats and the two HBM-traffic PMC passes for the bench
 # command (headline and track workloads), plus a calibration pass on the plain copy kernel; the summaries
 # (gpurun_out/<round>_*.md / .json, small) are what comes back — copy them into profiles/.
-#   tools/profile_round.sh r03
+#   tools/profile_round.sh r04
 # The track workload is profiled over 300 launches (bench.py's own default for `--workload track`): the clocks need
 # 50-150 ms under load to settle, and the summary quotes the launches after the first 160 ms ("settled") beside the
 # average over all of them, so that it can be compared with the settled figure `extra.track` carries in the bench line.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 REPO=$PWD
 OUT=/tmp/prof_$R
 rm -rf $OUT; mkdir -p $OUT $REPO/gpurun_out
