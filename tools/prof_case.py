@@ -1,5 +1,5 @@
 """Run ONE plan a few times (for rocprofv3): python tools/prof_case.py CASE [key=value ...]
-CASE: track600 | track300f | const<shift> | synth<rows>;  options: dpx_options fields, variant=N, pair=i16:i16, iters=N"""
+CASE: track600 | track300f | const<shift> | synth<rows>;  options: dpx_options fields, variant=N, pair=i16:i16, iters=N, cast=legacy"""
 import calendar
 import os
 import sys
@@ -19,6 +19,7 @@ variant = int(kv.pop("variant", 3))
 iters = int(kv.pop("iters", 6))
 RATE = int(kv.pop("rate", RATE))
 geom = kv.pop("geom", None)
+cast = kv.pop("cast", "saturate")          # cast=legacy: dpx_set_i16_cast(DPX_CAST_LEGACY_X86)
 it, ot = pair.split(":")
 if case == "track600":
     segs = bench.track_segments(600, RATE, it, calendar.timegm((2015, 1, 22, 19, 48, 0)))
@@ -32,6 +33,7 @@ n = sum(c for c, _ in segs)
 ctx = doppler_amd.Context(0)
 ctx.set_tuning(*([int(t) for t in geom.split("x")] if geom else [0, 0]), variant)
 ctx.set_options(**{k: int(v) for k, v in kv.items()})
+ctx.set_i16_cast(cast == "legacy")
 plan = ctx.plan_segments(segs, RATE)
 dev = torch.device("cuda:0")
 x = (torch.randint(-23170, 23171, (2 * n,), dtype=torch.int16, device=dev) if it == "i16" else torch.rand(2 * n, device=dev) * 2 - 1)

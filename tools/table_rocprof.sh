@@ -61,6 +61,9 @@ row "3 Hz, sincos per sample, f32->f32" 16 const3 variant=1 pair=f32:f32 geom=25
 row "5001 Hz, sincos per sample, i16->i16" 8 const5001 variant=1
 row "5001 Hz, sincos per sample, f32->f32" 16 const5001 variant=1 pair=f32:f32 geom=256x1
 row "track replay 600 s, i16->i16" 8 track600
+row "legacy i16 cast: 5000 Hz (rows kernel), i16->i16" 8 const5000 cast=legacy
+row "legacy i16 cast: 5001 Hz (span kernel), i16->i16" 8 const5001 cast=legacy
+row "legacy i16 cast: track replay 600 s, i16->i16" 8 track600 cast=legacy
 row "track replay 300 s, f32->i16" 12 track300f pair=f32:i16
 row "track replay 300 s, f32->f32" 16 track300f pair=f32:f32
 row "track replay 300 s, i16->f32" 12 track300f pair=i16:f32
