@@ -1,5 +1,5 @@
 """The 600 s replay's one-second segments grouped by the rows of their walk matrix, each group timed as a plan of its own
-under several option sets (JSON list of dpx_options dicts in OPTS; default: walk kernel 4x2 against span kernel 8 / 16)."""
+under several option sets (JSON list of dpx_options dicts in OPTS; default: the planner's own shape against spans of 8 / 16)."""
 import calendar, json, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,7 +15,7 @@ for n, hz in segs:
     for e in edges:
         if e[0] <= rows < e[1]:
             classes[e].append((n, hz))
-shapes = [tuple(sorted(o.items())) for o in json.loads(os.environ.get("OPTS", '[{"walk_span":1,"walk_waves":4,"walk_rows":2},{"walk_span":8},{"walk_span":16}]'))]
+shapes = [tuple(sorted(o.items())) for o in json.loads(os.environ.get("OPTS", '[{},{"walk_span":8},{"walk_span":16}]'))]
 ctx = doppler_amd.Context(0)
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream()
