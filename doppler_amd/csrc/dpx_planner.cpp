@@ -358,17 +358,19 @@ WalkShape walk_shape(const PlanTuning &tn)
 }
 
 // One span of a matrix: `h` rows under `waves` wavefronts.
-//   h <= 4 (waves = 4): the workgroup takes 2 (h <= 2: 4) adjacent windows, 2 (1) wavefronts each — otherwise half
+//   h <= 5 (waves = 4): the workgroup takes 2 (h <= 3: 4) adjacent windows, 2 (1) wavefronts each — otherwise half
 //     (three quarters) of its wavefronts would hold no row.  Measured on the replay's seconds of 3-4 rows: 72 -> 78 % under
 //     two wavefronts per window, 0-2 rows: 54 -> 62 % (profiles/r04_walk.md).  In general: the largest 2^s <= 4 that divides
-//     the wavefronts and leaves (waves >> s) x 2 >= h.
+//     the wavefronts and leaves (waves >> s) x 2 + 1 >= h — one row more than a turn holds (one wavefront of the window
+//     takes a second turn) is still better than the next larger workgroup share: 3 rows under 1 wavefront per window 70 %
+//     against 58 under 2, 5 rows under 2 per window 78 against 71 under 4; from 6 rows on 4 per window wins (79 against 73-75).
 struct SpanShape { uint32_t wshift, upw; };
 SpanShape span_shape(uint32_t h, const WalkShape &g)
 {
     SpanShape sh = {0, 2};
     if (g.fixed) return sh;
     for (uint32_t s2 = kSpanMaxShift; s2 > 0; --s2) {
-        if (g.waves % (1u << s2) == 0 && (g.waves >> s2) * 2 >= h) { sh.wshift = s2; break; }
+        if (g.waves % (1u << s2) == 0 && (g.waves >> s2) * 2 + 1 >= h) { sh.wshift = s2; break; }
     }
     return sh;
 }

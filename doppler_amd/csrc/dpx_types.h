@@ -101,7 +101,7 @@ struct RowsArgs {
 // through LDS, and its wavefronts mix and store the rows, `upw` per wavefront per turn.
 // The launch is a list of spans (WalkSeg), stretch by stretch, each padded to a multiple of 8 workgroups.
 //
-// Short matrices (round 4).  A span of up to 4 rows leaves half or three quarters of a 4-wavefront workgroup without rows
+// Short matrices (round 4).  A span of up to 5 rows leaves half or three quarters of a 4-wavefront workgroup without rows
 // (the replay's seconds near the closest approach: periods above a quarter of a second), and measures 6-9 points better
 // under 2 wavefronts per window (profiles/r04_walk.md).  A launch has one workgroup size, so such a span's workgroups take
 // 2^wshift ADJACENT windows instead, WAVES >> wshift wavefronts each, one contiguous slice: every wavefront has rows, and

@@ -7,6 +7,9 @@ import bench, doppler_amd
 RATE = 1024000
 segs = bench.track_segments(600, RATE, "i16", calendar.timegm((2015, 1, 22, 19, 48, 0)))
 edges = [(0, 3), (3, 5), (5, 7), (7, 9), (9, 12), (12, 17), (17, 25), (25, 1 << 30)]
+if os.environ.get("EDGES"):     # e.g. EDGES=0,2,3,4,5,6,7,9 : finer classes (upper edge of the last one open)
+    e = [float(v) for v in os.environ["EDGES"].split(",")]
+    edges = [(e[i], e[i + 1]) for i in range(len(e) - 1)] + [(e[-1], 1 << 30)]
 classes = {e: [] for e in edges}
 for n, hz in segs:
     st, _ = doppler_amd.plan_describe([(n, hz)], RATE, samplenum=1)
@@ -54,6 +57,6 @@ for key in classes:
     share = row[0]["nseg"] / tot
     t_def += share / pct[shapes[0]]
     t_best += share / max(pct.values())
-    print("%-10s %5.1f%%  " % ("%d-%s" % (key[0], key[1] - 1 if key[1] < 1 << 29 else ""), 100 * share) + " ".join("%6.1f" % pct[s] for s in shapes))
+    print("%-10s %5.1f%%  " % ("%g-%s" % (key[0], ("%g" % key[1]) if key[1] < 1 << 29 else ""), 100 * share) + " ".join("%6.1f" % pct[s] for s in shapes))
 print("options:", [dict(s) for s in shapes])
 print("replay composed from the classes: o0 everywhere %.1f %%, best per class %.1f %%" % (1 / t_def, 1 / t_best))
