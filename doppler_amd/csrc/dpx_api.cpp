@@ -254,15 +254,19 @@ int materialize(dpx_ctx *ctx, const dpx::PlanResult &plan, DevPlan &dev, bool fm
 int run_plan(const dpx::PlanResult &plan, const DevPlan &dev, const void *d_in, int in_fmt, void *d_out,
              int out_fmt, bool fma, const dpx::LaunchGeom &g_in, void *st)
 {
-    // Tile-kernel geometry when the caller named none: 256 lanes x one vector, except for i16 output evaluated sample by
-    // sample (no tile tables), where 128 lanes x two vectors measures 2 points better (profiles/r02_walk.md, `--set geom`:
-    // i16->f32 sincos per sample 52.8 -> 62.8 %, tile tables 62-69 -> 66-71 %).  Both are 1024-sample tiles: the plan fits either.
+    // Tile-kernel geometry when the caller named none (all three are 1024-sample tiles: the plan fits any): 256 lanes x one
+    // vector for f32 output and for tile tables; for i16 output evaluated sample by sample 128 lanes x two vectors
+    // (profiles/r02_walk.md, `--set geom`: i16->f32 sincos per sample 52.8 -> 62.8 %, tile tables 62-69 -> 66-71 %), and ONE
+    // wavefront x four vectors for i16 -> i16: the per-sample path is bound by vector instructions, 8 of the 45 per sample
+    // are the tile's set-up (stretch lookup, phase of the tile, addresses), and sixteen samples per lane halve them
+    // (round 4, same box: 3 Hz 63.8 -> 66.1 %, 5001 Hz 60.0 -> 62.8; no gain for the pairs with an f32 side).
     dpx::LaunchGeom g = g_in;
     if (g.autosel && g.tile() == 1024u) {
         const bool wide = out_fmt == DPX_FMT_F32 || plan.tile_tables;
-        g.block = wide ? 256 : 128;
-        g.vecs = wide ? 1 : 2;
+        g.block = wide ? 256 : in_fmt == DPX_FMT_I16 ? 64 : 128;
+        g.vecs = wide ? 1 : in_fmt == DPX_FMT_I16 ? 4 : 2;
     }
+    if (g.block == 64 && !(in_fmt == DPX_FMT_I16 && out_fmt == DPX_FMT_I16)) { g.block = 128; g.vecs = 2; }   // 64 x 4 exists for i16 -> i16 only
     for (const dpx::Launch &ln : plan.launches) {
         int rc;
         if (ln.kind == 0)
@@ -636,12 +640,12 @@ int dpx_set_tuning(dpx_ctx *ctx, int block, int vecs, int variant)
         ctx->geom_auto = true;
         block = vecs = 0;
     }
-    if (block != 0 && block != 128 && block != 256) return fail(DPX_ERR_ARG, "block must be 128 or 256");
-    if (vecs != 0 && vecs != 1 && vecs != 2) return fail(DPX_ERR_ARG, "vecs must be 1 or 2");
-    {   // the two 1024-sample tiles that are built: 256 lanes x 1 vector, 128 x 2 (naming one half picks the other half to match)
-        int b = block ? block : (vecs ? (vecs == 1 ? 256 : 128) : ctx->block);
-        int v = vecs ? vecs : (block ? (block == 256 ? 1 : 2) : ctx->vecs);
-        if (b * v != 256) return fail(DPX_ERR_ARG, "tile geometry must be 256 x 1 or 128 x 2");
+    if (block != 0 && block != 64 && block != 128 && block != 256) return fail(DPX_ERR_ARG, "block must be 64, 128 or 256");
+    if (vecs != 0 && vecs != 1 && vecs != 2 && vecs != 4) return fail(DPX_ERR_ARG, "vecs must be 1, 2 or 4");
+    {   // the three 1024-sample tiles that are built: 256 lanes x 1 vector, 128 x 2, 64 x 4 (naming one half picks the other to match)
+        int b = block ? block : (vecs ? 256 / vecs : ctx->block);
+        int v = vecs ? vecs : (block ? 256 / block : ctx->vecs);
+        if (b * v != 256) return fail(DPX_ERR_ARG, "tile geometry must be 256 x 1, 128 x 2 or 64 x 4");
         if (block || vecs) { ctx->block = b; ctx->vecs = v; ctx->geom_auto = false; }
     }
     ctx->choice = choice_of(variant);

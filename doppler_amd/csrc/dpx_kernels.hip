@@ -137,6 +137,26 @@ __device__ __forceinline__ void store_quad(uint8_t *base, uint64_t g, const Quad
     for (int i = 0; i < Fmt<FMT>::kVecs; ++i) __builtin_nontemporal_store(q.v[i], p + i);
 }
 
+// the same at a byte address: the tile kernel keeps the tile's base in scalar registers and adds a 32-bit lane offset
+// (saddr + voffset + immediate instead of 64-bit address arithmetic per lane and vector)
+template <int FMT>
+__device__ __forceinline__ Quad<FMT> load_quad_at(const uint8_t *p)
+{
+    Quad<FMT> q;
+    const u32x4 *v = reinterpret_cast<const u32x4 *>(p);
+#pragma unroll
+    for (int i = 0; i < Fmt<FMT>::kVecs; ++i) q.v[i] = __builtin_nontemporal_load(v + i);
+    return q;
+}
+
+template <int FMT>
+__device__ __forceinline__ void store_quad_at(uint8_t *p, const Quad<FMT> &q)
+{
+    u32x4 *v = reinterpret_cast<u32x4 *>(p);
+#pragma unroll
+    for (int i = 0; i < Fmt<FMT>::kVecs; ++i) __builtin_nontemporal_store(q.v[i], v + i);
+}
+
 template <int FMT, bool RAW = false>
 __device__ __forceinline__ void quad_get(const Quad<FMT> &q, int k, float &re, float &im)
 {
@@ -405,12 +425,16 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
     const uint64_t t0 = tile * TILE;
     const bool in_mask = t0 >= ta.m0 && t0 + TILE <= ta.m1;
 
-    // request this lane's input right away; nothing below is needed for the addresses
+    // request this lane's input right away; nothing below is needed for the addresses.  Tile base: uniform (scalar
+    // registers); lane offset: 32 bits; the V vectors of a lane: immediate offsets.
+    constexpr uint32_t IBq = Fmt<IN_FMT>::kBytes * SPL, OBq = Fmt<OUT_FMT>::kBytes * SPL;      // bytes of four samples
+    const uint8_t *tin = in + t0 * Fmt<IN_FMT>::kBytes;
+    uint8_t *tout = out + t0 * Fmt<OUT_FMT>::kBytes;
+    const uint32_t lane_in = tid * IBq, lane_out = tid * OBq;
     Quad<IN_FMT> qin[V];
     if (in_mask) {
 #pragma unroll
-        for (int v = 0; v < V; ++v)
-            qin[v] = load_quad<IN_FMT>(in, t0 + (uint64_t)(v * BLOCK + tid) * SPL);
+        for (int v = 0; v < V; ++v) qin[v] = load_quad_at<IN_FMT>(tin + (lane_in + (uint32_t)v * (BLOCK * IBq)));
     }
 
     // stretch holding the first produced sample (uniform: scalar loads)
@@ -444,7 +468,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
                 mix(a, b, cs[k].x, cs[k].y, re[k], im[k]);
             }
             quad_set4<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(qo, re, im, legacy);
-            store_quad<OUT_FMT>(out, t0 + (uint64_t)(v * BLOCK + tid) * SPL, qo);
+            store_quad_at<OUT_FMT>(tout + (lane_out + (uint32_t)v * (BLOCK * OBq)), qo);
         }
     } else if (whole && (sg.period == 0 || sg.period >= 4)) {
         // ---- sincos per sample: periodic with period >= 4, or linear.  A lane's four consecutive counters go
@@ -452,8 +476,14 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
         const uint32_t P = sg.period;
         const uint64_t j0 = t0 - sg.first;
         uint32_t base;   // periodic: phase of t0 in [0, P); linear: the counter itself
-        if (P != 0) base = (uint32_t)(((uint64_t)(sg.n_start - 1u) + j0) % P);
-        else        base = sg.n_start + (uint32_t)j0;
+        if (P != 0) {
+            // (a 64-bit by 32-bit remainder is seventeen vector instructions per wavefront even for uniform operands; a
+            // stream below 2^32 samples past the stretch's start — any stream a GPU holds — takes the 32-bit one)
+            const uint64_t s64 = (uint64_t)(sg.n_start - 1u) + j0;
+            base = (s64 >> 32) == 0 ? (uint32_t)s64 % P : (uint32_t)(s64 % P);
+        } else {
+            base = sg.n_start + (uint32_t)j0;
+        }
         // whether the counter wraps inside this tile is the same for all its lanes (base is the tile's): almost every
         // tile takes the path with one addition per counter
         const bool wraps = P != 0 && base + TILE > P;
@@ -499,7 +529,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
                 mix(a, b, cs[k].x, cs[k].y, re[k], im[k]);
             }
             quad_set4<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(qo, re, im, legacy);
-            store_quad<OUT_FMT>(out, t0 + (uint64_t)(v * BLOCK + tid) * SPL, qo);
+            store_quad_at<OUT_FMT>(tout + (lane_out + (uint32_t)v * (BLOCK * OBq)), qo);
         }
     } else {
         // ---- ragged tile: mask edge, stream tail, or a tile that straddles stretches
@@ -1139,6 +1169,9 @@ static int tiles_t(const void *d_in, void *d_out, const DevSeg *d_segs, uint32_t
         return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                       \
     }
     DPX_CASE(128, 2) DPX_CASE(256, 1)
+    if constexpr (IN_FMT == DPX_FMT_I16 && OUT_FMT == DPX_FMT_I16) {       // one wavefront x 16 samples per lane: built for this pair only
+        DPX_CASE(64, 4)
+    }
 #undef DPX_CASE
     return DPX_ERR_ARG;
 }

@@ -105,8 +105,8 @@ int dpx_stream_get_stats(const dpx_stream *s, dpx_stream_stats *out);
 int dpx_debug_copy(dpx_ctx *ctx, const void *d_in, void *d_out, size_t n_bytes, void *hip_stream);
 
 /* Measurement knobs (0 keeps the current value); they apply to plans created afterwards.
- * block / vecs: tile-kernel geometry, lanes per workgroup and 4-sample groups per lane: 256 x 1 or 128 x 2 (the same
- *          1024-sample tile; the two shapes that are built).  Until a call names one, every launch picks between them
+ * block / vecs: tile-kernel geometry, lanes per workgroup and 4-sample groups per lane: 256 x 1, 128 x 2 or 64 x 4 (the same
+ *          1024-sample tile; the three shapes that are built).  Until a call names one, every launch picks between them
  *          from its output format and whether the plan has tile tables (measured: DESIGN.md section 4);
  *          block = vecs = -1 returns to that.
  * variant: 3 = auto: rows kernel (one period of correctors tabulated) for up to eight long stretches (const mode),

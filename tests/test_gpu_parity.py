@@ -266,7 +266,7 @@ def test_const_stream_bulk_vs_oracle(ctx, orc, intype, outtype):
     want, sn_w = orc.const_stream(x, intype, outtype, 5000, 1024000, threads=8)
     sn_w = orc.advance_samplenum(0, 5000.0, 1024000, n)
     try:
-        for variant, block, vecs in [(3, 256, 1), (4, 256, 1), (1, 256, 1), (2, 128, 2), (4, 128, 2), (1, 128, 2)]:
+        for variant, block, vecs in [(3, 256, 1), (4, 256, 1), (1, 256, 1), (2, 128, 2), (4, 128, 2), (1, 128, 2), (1, 64, 4), (4, 64, 4)]:
             ctx.set_tuning(block, vecs, variant)
             got, fin = run_bulk(ctx, x, intype, outtype, [(n, 5000.0)], 1024000)
             assert fin == sn_w
