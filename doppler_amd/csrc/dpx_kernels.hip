@@ -102,14 +102,19 @@ __device__ __forceinline__ uint32_t pack_i16(float re, float im)
 {
     constexpr float K = RAW ? 0x1.fffcp-1f /* 32767 / 32768, exact */ : 32767.0f;
     const f32x2 sc = f32x2{re, im} * K;                  // one v_pk_mul_f32, each product rounded on its own
-    if constexpr (LEGACY) {
+    if constexpr (LEGACY && RAW) {
+        // i16 in: |I|, |Q| <= 32768 and |c|, |s| <= 1, so |sc| < 65537 — no NaN, nothing near 2^31: truncate and wrap,
+        // as many instructions as the default cast (the replay under this mode ran 3 points behind with the tests below)
+        return ((uint32_t)f32_as_i32_sat(sc.x) & 0xffffu) | ((uint32_t)f32_as_i32_sat(sc.y) << 16);
+    } else if constexpr (LEGACY) {
         const uint32_t i = sc.x >= 2147483648.0f ? 0u : (uint32_t)f32_as_i32_sat(sc.x);
         const uint32_t q = sc.y >= 2147483648.0f ? 0u : (uint32_t)f32_as_i32_sat(sc.y);
         return (i & 0xffffu) | (q << 16);
+    } else {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        const s16x2 p = __builtin_amdgcn_cvt_pk_i16(f32_as_i32_sat(sc.x), f32_as_i32_sat(sc.y));
+        return __builtin_bit_cast(uint32_t, p);
     }
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
-    const s16x2 p = __builtin_amdgcn_cvt_pk_i16(f32_as_i32_sat(sc.x), f32_as_i32_sat(sc.y));
-    return __builtin_bit_cast(uint32_t, p);
 }
 
 template <int FMT> struct Fmt;
@@ -408,8 +413,13 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
 }
 
 // ---- tile kernel: any mixture of stretches; workgroup b handles tile tile_lo + b and exits
+#ifdef DPX_TILE_WAVES_PER_EU     // measurement builds (tools/build_variant.sh): ask for an occupancy instead of taking the allocator's
+#define DPX_TILE_OCC __attribute__((amdgpu_waves_per_eu(DPX_TILE_WAVES_PER_EU)))
+#else
+#define DPX_TILE_OCC
+#endif
 template <int IN_FMT, int OUT_FMT, bool FMA, int BLOCK, int V>
-__global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__ in,
+__global__ __launch_bounds__(BLOCK) DPX_TILE_OCC void tile_kernel(const uint8_t *__restrict__ in,
                                                      uint8_t *__restrict__ out,
                                                      const DevSeg *__restrict__ segs,
                                                      uint32_t n_segs,
@@ -431,10 +441,39 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
     const uint8_t *tin = in + t0 * Fmt<IN_FMT>::kBytes;
     uint8_t *tout = out + t0 * Fmt<OUT_FMT>::kBytes;
     const uint32_t lane_in = tid * IBq, lane_out = tid * OBq;
+    // f32 -> f32 (kPairs): a lane's four samples are two PAIRS, BLOCK * 2 samples apart — each 16-byte vector of a
+    // wavefront instruction is then adjacent to its neighbours' (a KiB per instruction) instead of every other 16 bytes of
+    // two KiB, the pattern that costs the span kernel 8 points (WalkVec::kSplit).  Sample k of vector v sits at tile offset
+    // lane_sample(v, k).
+    constexpr bool kPairs = IN_FMT == DPX_FMT_F32 && OUT_FMT == DPX_FMT_F32;
+    auto lane_sample = [&](int v, int k) -> uint32_t {
+        if constexpr (kPairs) return (uint32_t)v * (BLOCK * SPL) + (uint32_t)(k >> 1) * (BLOCK * 2u) + tid * 2u + (uint32_t)(k & 1);
+        else                  return (uint32_t)(v * BLOCK + tid) * SPL + (uint32_t)k;
+    };
+    auto tile_load = [&](int v) -> Quad<IN_FMT> {
+        if constexpr (kPairs) {
+            Quad<IN_FMT> q;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                q.v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tin + ((uint32_t)v * (BLOCK * IBq) + (uint32_t)i * (BLOCK * 16u) + tid * 16u)));
+            return q;
+        } else {
+            return load_quad_at<IN_FMT>(tin + (lane_in + (uint32_t)v * (BLOCK * IBq)));
+        }
+    };
+    auto tile_store = [&](int v, const Quad<OUT_FMT> &q) {
+        if constexpr (kPairs) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_nontemporal_store(q.v[i], reinterpret_cast<u32x4 *>(tout + ((uint32_t)v * (BLOCK * OBq) + (uint32_t)i * (BLOCK * 16u) + tid * 16u)));
+        } else {
+            store_quad_at<OUT_FMT>(tout + (lane_out + (uint32_t)v * (BLOCK * OBq)), q);
+        }
+    };
     Quad<IN_FMT> qin[V];
     if (in_mask) {
 #pragma unroll
-        for (int v = 0; v < V; ++v) qin[v] = load_quad_at<IN_FMT>(tin + (lane_in + (uint32_t)v * (BLOCK * IBq)));
+        for (int v = 0; v < V; ++v) qin[v] = tile_load(v);
     }
 
     // stretch holding the first produced sample (uniform: scalar loads)
@@ -455,10 +494,9 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
         const float2 *tab = lut_pool + sg.lut_off + ph;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const uint32_t e = (uint32_t)(v * BLOCK + tid) * SPL;
             float2 cs[SPL];
 #pragma unroll
-            for (int k = 0; k < (int)SPL; ++k) cs[k] = tab[e + k];
+            for (int k = 0; k < (int)SPL; ++k) cs[k] = tab[lane_sample(v, k)];
             Quad<OUT_FMT> qo;
             float re[SPL], im[SPL];
 #pragma unroll
@@ -468,7 +506,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
                 mix(a, b, cs[k].x, cs[k].y, re[k], im[k]);
             }
             quad_set4<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(qo, re, im, legacy);
-            store_quad_at<OUT_FMT>(tout + (lane_out + (uint32_t)v * (BLOCK * OBq)), qo);
+            tile_store(v, qo);
         }
     } else if (whole && (sg.period == 0 || sg.period >= 4)) {
         // ---- sincos per sample: periodic with period >= 4, or linear.  A lane's four consecutive counters go
@@ -499,23 +537,30 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
         }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            uint32_t t = base + (uint32_t)(v * BLOCK + tid) * SPL;     // periodic: < P + TILE
+            uint32_t t = base + lane_sample(v, 0);                      // periodic: < P + TILE
+            const uint32_t tb = base + lane_sample(v, 2);               // kPairs: the lane's second pair
             f32x2 cs[SPL];
             if (!wraps) {
                 const uint32_t n0 = P == 0 ? t : t + 1u;                // u32 arithmetic wraps like the reference's `+= 1`
+                const uint32_t n2 = kPairs ? (P == 0 ? tb : tb + 1u) : n0 + 2u;
                 if (small) {                                             // every counter of the tile below 2^24 (uniform)
-                    corrector4_consecutive<FMA>(sg.ratio, n0, cs, path);
+                    if constexpr (kPairs) corrector4_pairs<FMA>(sg.ratio, n0, n2, cs, path);
+                    else                  corrector4_consecutive<FMA>(sg.ratio, n0, cs, path);
                 } else {
-                    const uint32_t n[SPL] = {n0, n0 + 1u, n0 + 2u, n0 + 3u};
+                    const uint32_t n[SPL] = {n0, n0 + 1u, n2, n2 + 1u};
                     corrector4<FMA>(sg.ratio, n, cs, path);
                 }
             } else {
                 uint32_t n[SPL];
-                if (P >= TILE) t = t >= P ? t - P : t;                   // at most one wrap (uniform branch)
-                else           t %= P;
+                uint32_t tt[2] = {t, tb};
+#pragma unroll
+                for (int h = 0; h < (kPairs ? 2 : 1); ++h) {
+                    if (P >= TILE) tt[h] = tt[h] >= P ? tt[h] - P : tt[h];   // at most one wrap (uniform branch)
+                    else           tt[h] %= P;
+                }
 #pragma unroll
                 for (int k = 0; k < (int)SPL; ++k) {
-                    const uint32_t e = t + k;                            // P >= 4: at most one wrap
+                    const uint32_t e = kPairs ? tt[k >> 1] + (uint32_t)(k & 1) : tt[0] + (uint32_t)k;   // P >= 4: at most one wrap
                     n[k] = (e >= P ? e - P : e) + 1u;
                 }
                 corrector4<FMA>(sg.ratio, n, cs);
@@ -529,7 +574,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
                 mix(a, b, cs[k].x, cs[k].y, re[k], im[k]);
             }
             quad_set4<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(qo, re, im, legacy);
-            store_quad_at<OUT_FMT>(tout + (lane_out + (uint32_t)v * (BLOCK * OBq)), qo);
+            tile_store(v, qo);
         }
     } else {
         // ---- ragged tile: mask edge, stream tail, or a tile that straddles stretches

@@ -399,6 +399,14 @@ __device__ __forceinline__ void corrector4_consecutive(float ratio, uint32_t n0,
     corrector4_f<FMA>(ratio, sc_f32x2{f0, f0} + sc_f32x2{0.0f, 1.0f}, sc_f32x2{f0, f0} + sc_f32x2{2.0f, 3.0f}, cs, path);
 }
 
+// Two PAIRS of consecutive counters (na, na + 1, nb, nb + 1), all below 2^24: the tile kernel's f32 -> f32 lanes
+template <bool FMA>
+__device__ __forceinline__ void corrector4_pairs(float ratio, uint32_t na, uint32_t nb, sc_f32x2 cs[4], int path = kPathAny)
+{
+    const float fa = (float)na, fb = (float)nb;
+    corrector4_f<FMA>(ratio, sc_f32x2{fa, fa} + sc_f32x2{0.0f, 1.0f}, sc_f32x2{fb, fb} + sc_f32x2{0.0f, 1.0f}, cs, path);
+}
+
 // fl32 of the four counters given: the two f32 products of theta, then the path decision
 template <bool FMA>
 __device__ __forceinline__ void corrector4_f(float ratio, sc_f32x2 f01, sc_f32x2 f23, sc_f32x2 cs[4], int path)

@@ -5,12 +5,18 @@ sys.path.insert(0, ".")
 import torch, doppler_amd
 from tools.sweep import time_launches
 ctx = doppler_amd.Context(0)
-n = 268435456
+TRACK = len(sys.argv) > 1 and sys.argv[1] == "track"     # the 10-minute replay instead of the headline stream
+n = 614400000 if TRACK else 268435456
 dev = torch.device("cuda:0")
 x = torch.randint(-23170, 23171, (2 * n,), dtype=torch.int16, device=dev)
 big = torch.empty(4 * n + (64 << 20), dtype=torch.uint8, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-plan = ctx.plan_const(5000.0, 1024000, n)
+if TRACK:
+    import calendar, bench
+    segs = bench.track_segments(600, 1024000, "i16", calendar.timegm((2015, 1, 22, 19, 48, 0)))
+    plan = ctx.plan_segments(segs, 1024000, samplenum=0)
+else:
+    plan = ctx.plan_const(5000.0, 1024000, n)
 base = (big.data_ptr() + (2 << 20) - 1) // (2 << 20) * (2 << 20)
 print("in ptr %x  out base %x" % (x.data_ptr(), base))
 for off in [0, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 3 << 19, 2 << 20, 5 << 20, 16 << 20]:
