@@ -441,21 +441,48 @@ __global__ __launch_bounds__(BLOCK) DPX_TILE_OCC void tile_kernel(const uint8_t 
     const uint8_t *tin = in + t0 * Fmt<IN_FMT>::kBytes;
     uint8_t *tout = out + t0 * Fmt<OUT_FMT>::kBytes;
     const uint32_t lane_in = tid * IBq, lane_out = tid * OBq;
-    // f32 -> f32 (kPairs): a lane's four samples are two PAIRS, BLOCK * 2 samples apart — each 16-byte vector of a
-    // wavefront instruction is then adjacent to its neighbours' (a KiB per instruction) instead of every other 16 bytes of
-    // two KiB, the pattern that costs the span kernel 8 points (WalkVec::kSplit).  Sample k of vector v sits at tile offset
-    // lane_sample(v, k).
-    constexpr bool kPairs = IN_FMT == DPX_FMT_F32 && OUT_FMT == DPX_FMT_F32;
+    // f32 output (kPairs): a lane's four samples are two PAIRS, BLOCK * 2 samples apart — each vector of a wavefront
+    // instruction is then adjacent to its neighbours' (16-byte stores: a KiB per instruction) instead of every other
+    // 16 bytes of two KiB, the pattern that costs the span kernel 8 points (WalkVec::kSplit).  The input side follows:
+    // two 16-byte loads (f32) or two 8-byte loads (i16: 512 contiguous bytes per instruction, what the rows kernel reads
+    // for this pair).
+    // f32 -> i16 (kXpose): pairs as well, 128 samples apart inside the 256 samples of the lane's WAVEFRONT, so that the
+    // packed results can change lanes through a wavefront-private KiB of LDS and leave as one 16-byte store per lane
+    // (pairs stored as they are would be 8-byte stores: 2.4 TB/s in the span kernel, hence its WalkVec::kTranspose).
+    // Sample k of vector v sits at tile offset lane_sample(v, k).
+#ifndef DPX_TILE_XPOSE
+#define DPX_TILE_XPOSE 1
+#endif
+    constexpr bool kPairs = OUT_FMT == DPX_FMT_F32;
+    constexpr bool kXpose = DPX_TILE_XPOSE && IN_FMT == DPX_FMT_F32 && OUT_FMT == DPX_FMT_I16;
+    constexpr bool kTwoPairs = kPairs || kXpose;          // a lane's samples: two pairs (else four consecutive ones)
+    const uint32_t wv = tid >> 6, ln = tid & 63u;
+    __shared__ __attribute__((aligned(16))) uint32_t xpose_lds[kXpose ? BLOCK * SPL : 4];
     auto lane_sample = [&](int v, int k) -> uint32_t {
         if constexpr (kPairs) return (uint32_t)v * (BLOCK * SPL) + (uint32_t)(k >> 1) * (BLOCK * 2u) + tid * 2u + (uint32_t)(k & 1);
+        else if constexpr (kXpose) return (uint32_t)v * (BLOCK * SPL) + wv * 256u + (uint32_t)(k >> 1) * 128u + ln * 2u + (uint32_t)(k & 1);
         else                  return (uint32_t)(v * BLOCK + tid) * SPL + (uint32_t)k;
     };
     auto tile_load = [&](int v) -> Quad<IN_FMT> {
         if constexpr (kPairs) {
             Quad<IN_FMT> q;
+            const uint8_t *pv = tin + (uint32_t)v * (BLOCK * IBq);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                q.v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tin + ((uint32_t)v * (BLOCK * IBq) + (uint32_t)i * (BLOCK * 16u) + tid * 16u)));
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (IN_FMT == DPX_FMT_F32) {
+                    q.v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(pv + ((uint32_t)i * (BLOCK * 16u) + tid * 16u)));
+                } else {
+                    const u32x2 h = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pv + ((uint32_t)i * (BLOCK * 8u) + tid * 8u)));
+                    q.v[0][2 * i] = h[0];
+                    q.v[0][2 * i + 1] = h[1];
+                }
+            }
+            return q;
+        } else if constexpr (kXpose) {
+            Quad<IN_FMT> q;
+            const uint8_t *pv = tin + ((uint32_t)v * (BLOCK * IBq) + wv * 2048u + ln * 16u);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) q.v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(pv + (uint32_t)i * 1024u));
             return q;
         } else {
             return load_quad_at<IN_FMT>(tin + (lane_in + (uint32_t)v * (BLOCK * IBq)));
@@ -466,6 +493,17 @@ __global__ __launch_bounds__(BLOCK) DPX_TILE_OCC void tile_kernel(const uint8_t 
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 __builtin_nontemporal_store(q.v[i], reinterpret_cast<u32x4 *>(tout + ((uint32_t)v * (BLOCK * OBq) + (uint32_t)i * (BLOCK * 16u) + tid * 16u)));
+        } else if constexpr (kXpose) {
+            // q.v[0] = {pair A, pair B} of this lane; the wavefront's 256 packed samples in order, then 16 bytes per lane
+            // (same wavefront: LDS operations execute in order; the barrier keeps the compiler from moving them)
+            uint32_t *xrow = xpose_lds + wv * 256u;
+            __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<u32x2 *>(xrow + ln * 2u) = u32x2{q.v[0][0], q.v[0][1]};
+            *reinterpret_cast<u32x2 *>(xrow + 128u + ln * 2u) = u32x2{q.v[0][2], q.v[0][3]};
+            __builtin_amdgcn_wave_barrier();
+            u32x4 o = *reinterpret_cast<const u32x4 *>(xrow + ln * 4u);
+            asm volatile("" : "+v"(o));
+            __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(tout + ((uint32_t)v * (BLOCK * OBq) + wv * 1024u + ln * 16u)));
         } else {
             store_quad_at<OUT_FMT>(tout + (lane_out + (uint32_t)v * (BLOCK * OBq)), q);
         }
@@ -538,13 +576,13 @@ __global__ __launch_bounds__(BLOCK) DPX_TILE_OCC void tile_kernel(const uint8_t 
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             uint32_t t = base + lane_sample(v, 0);                      // periodic: < P + TILE
-            const uint32_t tb = base + lane_sample(v, 2);               // kPairs: the lane's second pair
+            const uint32_t tb = base + lane_sample(v, 2);               // pairs: the lane's second pair
             f32x2 cs[SPL];
             if (!wraps) {
                 const uint32_t n0 = P == 0 ? t : t + 1u;                // u32 arithmetic wraps like the reference's `+= 1`
-                const uint32_t n2 = kPairs ? (P == 0 ? tb : tb + 1u) : n0 + 2u;
+                const uint32_t n2 = kTwoPairs ? (P == 0 ? tb : tb + 1u) : n0 + 2u;
                 if (small) {                                             // every counter of the tile below 2^24 (uniform)
-                    if constexpr (kPairs) corrector4_pairs<FMA>(sg.ratio, n0, n2, cs, path);
+                    if constexpr (kTwoPairs) corrector4_pairs<FMA>(sg.ratio, n0, n2, cs, path);
                     else                  corrector4_consecutive<FMA>(sg.ratio, n0, cs, path);
                 } else {
                     const uint32_t n[SPL] = {n0, n0 + 1u, n2, n2 + 1u};
@@ -554,13 +592,13 @@ __global__ __launch_bounds__(BLOCK) DPX_TILE_OCC void tile_kernel(const uint8_t 
                 uint32_t n[SPL];
                 uint32_t tt[2] = {t, tb};
 #pragma unroll
-                for (int h = 0; h < (kPairs ? 2 : 1); ++h) {
+                for (int h = 0; h < (kTwoPairs ? 2 : 1); ++h) {
                     if (P >= TILE) tt[h] = tt[h] >= P ? tt[h] - P : tt[h];   // at most one wrap (uniform branch)
                     else           tt[h] %= P;
                 }
 #pragma unroll
                 for (int k = 0; k < (int)SPL; ++k) {
-                    const uint32_t e = kPairs ? tt[k >> 1] + (uint32_t)(k & 1) : tt[0] + (uint32_t)k;   // P >= 4: at most one wrap
+                    const uint32_t e = kTwoPairs ? tt[k >> 1] + (uint32_t)(k & 1) : tt[0] + (uint32_t)k;   // P >= 4: at most one wrap
                     n[k] = (e >= P ? e - P : e) + 1u;
                 }
                 corrector4<FMA>(sg.ratio, n, cs);
@@ -644,38 +682,49 @@ __device__ __forceinline__ void leftover_block(const uint8_t *__restrict__ in, u
 #pragma unroll
         for (uint32_t q = tid; q < 256u; q += THREADS) {
         if (o0 + kLeftBlock <= lr.len && (P == 0 || P >= 4)) {
-            // a whole block: four CONSECUTIVE samples per thread, moved as 16-byte vectors (a block starts wherever its
-            // range does, so the vectors are only sample-aligned: the hardware takes unaligned global accesses)
+            // a whole block: four samples per thread slot, moved as 16-byte vectors (a block starts wherever its range
+            // does, so the vectors are only sample-aligned: the hardware takes unaligned global accesses).  i16 output:
+            // four CONSECUTIVE samples; f32 output: two PAIRS half a block apart, so that the 16-byte stores of a wavefront
+            // instruction are adjacent (the tile kernel's kPairs, same reason).
             constexpr int IB = Fmt<IN_FMT>::kBytes, OB = Fmt<OUT_FMT>::kBytes;
+            constexpr bool kPairs = OUT_FMT == DPX_FMT_F32;
             typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-            const uint64_t g = g0 + q * 4u;
-            u32x4_u qv[Fmt<IN_FMT>::kVecs];
+            typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+            const uint32_t oa = kPairs ? q * 2u : q * 4u;                       // offsets of the lane's samples 0 and 2 in the block
+            const uint32_t ob = kPairs ? kLeftBlock / 2u + q * 2u : q * 4u + 2u;
+            Quad<IN_FMT> qi;
+            if constexpr (!kPairs) {
 #pragma unroll
-            for (int i = 0; i < Fmt<IN_FMT>::kVecs; ++i) qv[i] = *(reinterpret_cast<const u32x4_u *>(in + g * IB) + i);
+                for (int i = 0; i < Fmt<IN_FMT>::kVecs; ++i) qi.v[i] = *(reinterpret_cast<const u32x4_u *>(in + (g0 + oa) * IB) + i);
+            } else if constexpr (IN_FMT == DPX_FMT_F32) {
+                qi.v[0] = *reinterpret_cast<const u32x4_u *>(in + (g0 + oa) * IB);
+                qi.v[1] = *reinterpret_cast<const u32x4_u *>(in + (g0 + ob) * IB);
+            } else {
+                const u32x2_u ha = *reinterpret_cast<const u32x2_u *>(in + (g0 + oa) * IB);
+                const u32x2_u hb = *reinterpret_cast<const u32x2_u *>(in + (g0 + ob) * IB);
+                qi.v[0] = u32x4{ha[0], ha[1], hb[0], hb[1]};
+            }
             f32x2 cs[4];
-            uint32_t t = base + q * 4u;
+            uint32_t ta = base + oa, tb = base + ob;
             if ((P == 0 || base + kLeftBlock <= P) && base < (1u << 24) - kLeftBlock - 1u) {
                 // no wrap inside the block and every counter below 2^24 (uniform): the usual case, lead-ins above all
-                corrector4_consecutive<FMA>(sg.ratio, P == 0 ? t : t + 1u, cs);
+                if constexpr (kPairs) corrector4_pairs<FMA>(sg.ratio, P == 0 ? ta : ta + 1u, P == 0 ? tb : tb + 1u, cs);
+                else                  corrector4_consecutive<FMA>(sg.ratio, P == 0 ? ta : ta + 1u, cs);
             } else {
                 uint32_t n[4];
                 if (P == 0) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) n[k] = t + k;
+                    n[0] = ta; n[1] = ta + 1u; n[2] = tb; n[3] = tb + 1u;
                 } else {
-                    if (P >= kLeftBlock) t = t >= P ? t - P : t;      // base < P: at most one wrap
-                    else                 t %= P;
+                    if (P >= kLeftBlock) { ta = ta >= P ? ta - P : ta; tb = tb >= P ? tb - P : tb; }   // base < P: at most one wrap
+                    else                 { ta %= P; tb %= P; }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const uint32_t ee = t + k;                  // P >= 4: at most one wrap
+                        const uint32_t ee = (k < 2 ? ta : tb) + (uint32_t)(k & 1);   // P >= 4: at most one wrap
                         n[k] = (ee >= P ? ee - P : ee) + 1u;
                     }
                 }
                 corrector4<FMA>(sg.ratio, n, cs);
             }
-            Quad<IN_FMT> qi;
-#pragma unroll
-            for (int i = 0; i < Fmt<IN_FMT>::kVecs; ++i) qi.v[i] = qv[i];
             Quad<OUT_FMT> qo;
             float re[4], im[4];
 #pragma unroll
@@ -685,10 +734,16 @@ __device__ __forceinline__ void leftover_block(const uint8_t *__restrict__ in, u
                 mix(a, bq, cs[k].x, cs[k].y, re[k], im[k]);
             }
             quad_set4<OUT_FMT, kRawI16<IN_FMT, OUT_FMT>>(qo, re, im, legacy);
+            if constexpr (!kPairs) {
 #pragma unroll
-            for (int i = 0; i < Fmt<OUT_FMT>::kVecs; ++i) {
-                const u32x4_u o = qo.v[i];
-                *(reinterpret_cast<u32x4_u *>(out + g * OB) + i) = o;
+                for (int i = 0; i < Fmt<OUT_FMT>::kVecs; ++i) {
+                    const u32x4_u o = qo.v[i];
+                    *(reinterpret_cast<u32x4_u *>(out + (g0 + oa) * OB) + i) = o;
+                }
+            } else {
+                const u32x4_u o0 = qo.v[0], o1 = qo.v[1];
+                *reinterpret_cast<u32x4_u *>(out + (g0 + oa) * OB) = o0;
+                *reinterpret_cast<u32x4_u *>(out + (g0 + ob) * OB) = o1;
             }
         } else {
             // the last block of a range (or a period below 4): sample by sample, o = q + k * 256

@@ -364,6 +364,11 @@ def cases(which):
             for span in (16, 32, 64):
                 c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, dict(walk_span=span, walk_waves=waves)))
                 c.append(("const 5001 Hz", lambda f: const_segs(5001), "i16:i16", 3, dict(walk_span=span, walk_waves=waves)))
+    if which == "persample4":    # the per-sample tile path, every format pair and tile geometry
+        for pair in ("i16:i16", "f32:f32", "f32:i16", "i16:f32"):
+            for geom in ((128, 2), (256, 1)) + (((64, 4),) if pair == "i16:i16" else ()):
+                for shift in (3, 5001):
+                    c.append(("const %d Hz, sincos per sample" % shift, lambda f, s=shift: const_segs(s), pair, 1, dict(_geom=geom)))
     if which == "geom":          # tile-kernel geometry per format pair: sincos per sample and tile tables
         for pair in ("i16:i16", "f32:f32", "f32:i16", "i16:f32"):
             for geom in ((128, 2), (256, 1), (128, 1), (256, 2)):
@@ -378,7 +383,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
     ap.add_argument("--shuffle", action="store_true", help="time the cases in a different order every round")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3", "pairs", "pairs2", "rowrule", "pairs3", "shapes", "pairs4", "tshape", "longp", "route2", "sincos1"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3", "pairs", "pairs2", "rowrule", "pairs3", "shapes", "pairs4", "tshape", "longp", "route2", "sincos1", "persample4"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)

@@ -11,7 +11,7 @@ for r in $(seq $ROUNDS); do
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print('  %-40s %-8s %-44s %6.1f' % (d['case'][:40], d['pair'], str(d.get('opts'))[:44], d['pct_peak']))"
+        d = json.loads(l); print('  %-40s %-8s %-9s %-36s %6.1f' % (d['case'][:40], d['pair'], 'x'.join(map(str, d.get('geom', []))), str(d.get('opts'))[:36], d['pct_peak']))"
   done
 done
 cp /tmp/ab_cur.so doppler_amd/lib/libdoppler_hip.so

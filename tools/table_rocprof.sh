@@ -57,9 +57,13 @@ row "7777.77 Hz (P=28043)" 8 const7777.77
 row "-5234.17 Hz (P=107405)" 8 const-5234.17
 row "3 Hz (P=1024000)" 8 const3
 row "3 Hz, sincos per sample (variant 1), i16->i16" 8 const3 variant=1
-row "3 Hz, sincos per sample, f32->f32" 16 const3 variant=1 pair=f32:f32 geom=256x1
+row "3 Hz, sincos per sample, f32->f32" 16 const3 variant=1 pair=f32:f32
 row "5001 Hz, sincos per sample, i16->i16" 8 const5001 variant=1
-row "5001 Hz, sincos per sample, f32->f32" 16 const5001 variant=1 pair=f32:f32 geom=256x1
+row "5001 Hz, sincos per sample, f32->f32" 16 const5001 variant=1 pair=f32:f32
+row "5001 Hz, sincos per sample, i16->f32" 12 const5001 variant=1 pair=i16:f32
+row "5001 Hz, sincos per sample, f32->i16" 12 const5001 variant=1 pair=f32:i16
+row "3 Hz, sincos per sample, i16->f32" 12 const3 variant=1 pair=i16:f32
+row "3 Hz, sincos per sample, f32->i16" 12 const3 variant=1 pair=f32:i16
 row "track replay 600 s, i16->i16" 8 track600
 row "legacy i16 cast: 5000 Hz (rows kernel), i16->i16" 8 const5000 cast=legacy
 row "legacy i16 cast: 5001 Hz (span kernel), i16->i16" 8 const5001 cast=legacy
