@@ -255,11 +255,12 @@ int run_plan(const dpx::PlanResult &plan, const DevPlan &dev, const void *d_in, 
              int out_fmt, bool fma, const dpx::LaunchGeom &g_in, void *st)
 {
     // Tile-kernel geometry when the caller named none (all three are 1024-sample tiles: the plan fits any): 256 lanes x one
-    // vector for f32 output and for tile tables; for i16 output evaluated sample by sample 128 lanes x two vectors
-    // (profiles/r02_walk.md, `--set geom`: i16->f32 sincos per sample 52.8 -> 62.8 %, tile tables 62-69 -> 66-71 %), and ONE
-    // wavefront x four vectors for i16 -> i16: the per-sample path is bound by vector instructions, 8 of the 45 per sample
-    // are the tile's set-up (stretch lookup, phase of the tile, addresses), and sixteen samples per lane halve them
-    // (round 4, same box: 3 Hz 63.8 -> 66.1 %, 5001 Hz 60.0 -> 62.8; no gain for the pairs with an f32 side).
+    // vector for f32 output and for tile tables; 128 lanes x two vectors for f32 -> i16; ONE wavefront x four vectors for
+    // i16 -> i16, whose per-sample path is bound by vector instructions: 8 of the 45 per sample were the tile's set-up
+    // (stretch lookup, phase of the tile, addresses), and sixteen samples per lane halve them.  Round 4, sincos per sample,
+    // 3 Hz / 5001 Hz on one box (profiles/raw/r04_ab_persample4.log): i16 -> i16 64x4 73 / 65 % (128x2 66 / 61, 256x1 59 / 57);
+    // f32 -> f32 256x1 78 / 78 (128x2 76 / 76); f32 -> i16 128x2 78.5 / 79.5 (256x1 79.5 / 75.5); i16 -> f32 256x1 80 / 76
+    // (128x2 75 / 75).
     dpx::LaunchGeom g = g_in;
     if (g.autosel && g.tile() == 1024u) {
         const bool wide = out_fmt == DPX_FMT_F32 || plan.tile_tables;

@@ -413,13 +413,8 @@ __global__ __launch_bounds__(kRowsLanes) void rows_kernel(const uint8_t *__restr
 }
 
 // ---- tile kernel: any mixture of stretches; workgroup b handles tile tile_lo + b and exits
-#ifdef DPX_TILE_WAVES_PER_EU     // measurement builds (tools/build_variant.sh): ask for an occupancy instead of taking the allocator's
-#define DPX_TILE_OCC __attribute__((amdgpu_waves_per_eu(DPX_TILE_WAVES_PER_EU)))
-#else
-#define DPX_TILE_OCC
-#endif
 template <int IN_FMT, int OUT_FMT, bool FMA, int BLOCK, int V>
-__global__ __launch_bounds__(BLOCK) DPX_TILE_OCC void tile_kernel(const uint8_t *__restrict__ in,
+__global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__ in,
                                                      uint8_t *__restrict__ out,
                                                      const DevSeg *__restrict__ segs,
                                                      uint32_t n_segs,
@@ -449,12 +444,10 @@ __global__ __launch_bounds__(BLOCK) DPX_TILE_OCC void tile_kernel(const uint8_t 
     // f32 -> i16 (kXpose): pairs as well, 128 samples apart inside the 256 samples of the lane's WAVEFRONT, so that the
     // packed results can change lanes through a wavefront-private KiB of LDS and leave as one 16-byte store per lane
     // (pairs stored as they are would be 8-byte stores: 2.4 TB/s in the span kernel, hence its WalkVec::kTranspose).
-    // Sample k of vector v sits at tile offset lane_sample(v, k).
-#ifndef DPX_TILE_XPOSE
-#define DPX_TILE_XPOSE 1
-#endif
+    // Sample k of vector v sits at tile offset lane_sample(v, k).  (256 lanes x one vector use 72-78 vector registers,
+    // six wavefronts per SIMD; a build held to eight by amdgpu_waves_per_eu spills and loses 1-3 points.)
     constexpr bool kPairs = OUT_FMT == DPX_FMT_F32;
-    constexpr bool kXpose = DPX_TILE_XPOSE && IN_FMT == DPX_FMT_F32 && OUT_FMT == DPX_FMT_I16;
+    constexpr bool kXpose = IN_FMT == DPX_FMT_F32 && OUT_FMT == DPX_FMT_I16;
     constexpr bool kTwoPairs = kPairs || kXpose;          // a lane's samples: two pairs (else four consecutive ones)
     const uint32_t wv = tid >> 6, ln = tid & 63u;
     __shared__ __attribute__((aligned(16))) uint32_t xpose_lds[kXpose ? BLOCK * SPL : 4];
