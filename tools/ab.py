@@ -364,6 +364,17 @@ def cases(which):
             for span in (16, 32, 64):
                 c.append(("track 600 s replay", lambda f: track_segs(600, f), "i16:i16", 3, dict(walk_span=span, walk_waves=waves)))
                 c.append(("const 5001 Hz", lambda f: const_segs(5001), "i16:i16", 3, dict(walk_span=span, walk_waves=waves)))
+    if which == "pairshape":     # replays with an f32 side: plans finalized for another (wavefronts, rows per span) than i16 -> i16's
+        cand = {"f32:f32": ((2, 4), (2, 6), (4, 10), (4, 6)), "f32:i16": ((5, 6), (5, 8), (8, 10), (4, 4), (4, 6)), "i16:f32": ((4, 10), (4, 12), (4, 16), (2, 8))}
+        for pair, shapes in cand.items():
+            c.append(("track 300 s replay", lambda f: track_segs(300, f), pair, 3, dict(_geom=(0, 0))))
+            for waves, span in shapes:
+                c.append(("track 300 s replay", lambda f: track_segs(300, f), pair, 3, dict(_geom=(0, 0), walk_waves=waves, walk_span=span)))
+    if which == "route3":        # pairs with an f32 side: the default plan (span kernel) against every corrector per sample (tile kernel)
+        for pair in ("f32:i16", "i16:f32", "f32:f32"):
+            for variant in (3, 1):
+                c.append(("track 300 s replay", lambda f: track_segs(300, f), pair, variant, dict(_geom=(0, 0))))     # (0, 0): the library's own choice
+                c.append(("const 5001 Hz", lambda f: const_segs(5001), pair, variant, dict(_geom=(0, 0))))
     if which == "persample4":    # the per-sample tile path, every format pair and tile geometry
         for pair in ("i16:i16", "f32:f32", "f32:i16", "i16:f32"):
             for geom in ((128, 2), (256, 1)) + (((64, 4),) if pair == "i16:i16" else ()):
@@ -383,7 +394,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
     ap.add_argument("--shuffle", action="store_true", help="time the cases in a different order every round")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3", "pairs", "pairs2", "rowrule", "pairs3", "shapes", "pairs4", "tshape", "longp", "route2", "sincos1", "persample4"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3", "pairs", "pairs2", "rowrule", "pairs3", "shapes", "pairs4", "tshape", "longp", "route2", "sincos1", "persample4", "route3", "pairshape"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)

@@ -1,6 +1,7 @@
 set -u
 mkdir -p gpurun_out
-SUFFIX=_box2 timeout 2400 tools/table_rocprof.sh > /dev/null 2>&1; echo "table rc=$?"
-timeout 900 python bench.py > gpurun_out/r04_bench_line_box2.json 2> gpurun_out/r04_bench_stderr.log; echo "bench rc=$?"
-python -c "
-import json; b=json.loads(open('gpurun_out/r04_bench_line_box2.json').read()); print(b['value'], b['roofline']['frac'], b['roofline']['traffic'], b['roofline'].get('frac_rocprof'), b['extra']['track']['roofline']['frac'], b['extra']['track']['roofline'].get('frac_rocprof'), b['per_rank'][0]['pci_bus_id'])"
+timeout 1200 python tools/ab.py --set pairshape --rounds 10 --iters 10 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print('%-24s %-8s %-40s %-40s %6.1f' % (d['case'][:24], d['pair'], str(d['opts']), d.get('kernel', '')[:40], d['pct_peak']))" | tee gpurun_out/r04b_pairshape.log
