@@ -532,6 +532,44 @@ def test_span_kernel_random_plans(ctx, orc):
     assert used_walk >= 5      # many of these plans really run on the span kernel
 
 
+@pytest.mark.parametrize("variant", [1, 4])
+def test_tile_kernel_random_plans(ctx, orc, variant):
+    """The tile kernel alone (variant 1: every corrector evaluated per sample; 4: tile tables where they fit) on seeded
+    random plans of 3-12 segments whose shifts give periods below a tile (the per-entry modulo), periods that wrap inside
+    tiles, million-sample periods and stretches that never reset; every format pair and every tile shape built for it.
+    Which four samples a lane takes depends on the pair (four consecutive ones, two pairs half a block apart, two pairs
+    inside the wavefront's 256 samples with an exchange through LDS): each must reproduce the oracle byte for byte,
+    ragged segment boundaries and stream tail included."""
+    rng = np.random.default_rng(977 + variant)
+    shapes = {("i16", "i16"): [(0, 0), (64, 4), (128, 2), (256, 1)], ("f32", "i16"): [(0, 0), (128, 2), (256, 1)],
+              ("i16", "f32"): [(0, 0), (128, 2), (256, 1)], ("f32", "f32"): [(0, 0), (128, 2), (256, 1)]}
+    try:
+        for case in range(12):
+            rate = int(rng.choice([48000, 256000, 1024000]))
+            segs = []
+            for _ in range(int(rng.integers(3, 13))):
+                kind = int(rng.integers(0, 5))
+                hz = (float(np.float32(rng.uniform(-11000, 11000))) if kind == 0 else          # arbitrary: period anything
+                      float(np.float32(rate / int(rng.choice([2, 3, 5, 64, 500, 1000])))) if kind == 1 else   # short periods
+                      float(np.float32(rng.integers(1, 40))) if kind == 2 else                  # periods of rate / k samples
+                      float(np.float32(rng.uniform(1e-4, 1e-2))) if kind == 3 else              # never resets within the segment
+                      0.0)
+                cnt = int(rng.integers(1, 40)) * 1024 + (0 if rng.random() < 0.5 else int(rng.integers(1, 1024)))
+                segs.append((cnt, hz))
+            intype, outtype = [("i16", "i16"), ("f32", "i16"), ("i16", "f32"), ("f32", "f32")][case % 4]
+            sn0 = int(rng.choice([0, 1, 777, (1 << 24) - 5000]))
+            n = sum(c for c, _ in segs)
+            x = make_iq(intype, n, 8100 + case, full_scale=(case % 2 == 0))
+            want, sn = oracle_segments(orc, x, intype, outtype, segs, rate, sn0)
+            for block, vecs in shapes[(intype, outtype)]:
+                ctx.set_tuning(block, vecs, variant)
+                got, fin = run_bulk(ctx, x, intype, outtype, segs, rate, sn0=sn0)
+                assert fin == sn, (case, segs[:3])
+                assert_same_bytes(got, want, outtype, "tile plan %d variant %d %dx%d (%d segments, %s->%s)" % (case, variant, block, vecs, len(segs), intype, outtype))
+    finally:
+        ctx.set_tuning(-1, -1, 3)
+
+
 def test_kernels_stay_inside_the_output_buffer(ctx, orc):
     """Guard bands of 64 KiB before and after the output stay untouched by every kernel choice (the span kernel masks the
     lanes past a row, the rows kernel pads its grid, tiles are masked)."""
