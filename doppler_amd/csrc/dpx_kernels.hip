@@ -438,7 +438,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const uint8_t *__restrict__
     const uint32_t lane_in = tid * IBq, lane_out = tid * OBq;
     // f32 output (kPairs): a lane's four samples are two PAIRS, BLOCK * 2 samples apart — each vector of a wavefront
     // instruction is then adjacent to its neighbours' (16-byte stores: a KiB per instruction) instead of every other
-    // 16 bytes of two KiB, the pattern that costs the span kernel 8 points (WalkVec::kSplit).  The input side follows:
+    // 16 bytes of two KiB (16-byte accesses at a 32-byte lane stride: 5.0 TB/s where the span kernel's f32 -> i16 rows
+    // were first tried that way, and 51-68 % of the peak on this kernel's per-sample path).  The input side follows:
     // two 16-byte loads (f32) or two 8-byte loads (i16: 512 contiguous bytes per instruction, what the rows kernel reads
     // for this pair).
     // f32 -> i16 (kXpose): pairs as well, 128 samples apart inside the 256 samples of the lane's WAVEFRONT, so that the
@@ -668,8 +669,13 @@ __device__ __forceinline__ void leftover_block(const uint8_t *__restrict__ in, u
         const uint32_t P = sg.period;
         const uint64_t j0 = g0 - sg.first;
         uint32_t base;   // periodic: phase of g0 in [0, P); linear: the counter itself
-        if (P != 0) base = (uint32_t)(((uint64_t)(sg.n_start - 1u) + j0) % P);
-        else        base = sg.n_start + (uint32_t)j0;
+        if (P != 0) {
+            // (the tile kernel's note: a 64-bit remainder is seventeen vector instructions even for uniform operands)
+            const uint64_t s64 = (uint64_t)(sg.n_start - 1u) + j0;
+            base = (s64 >> 32) == 0 ? (uint32_t)s64 % P : (uint32_t)(s64 % P);
+        } else {
+            base = sg.n_start + (uint32_t)j0;
+        }
         static_assert(kLeftBlock == 4 * 256, "a leftover block is four samples for each of 256 thread slots");
         // 256 thread slots q; a workgroup of fewer threads takes them in turns (compile-time trip count)
 #pragma unroll
