@@ -177,7 +177,8 @@ def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True):
         prof = profiled("track") if world == 1 else None
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": prof["hbm_bytes_per_launch"] if prof else None,
-                "kernel": "dpx::span_kernel" if layout["walk_launches"] else "dpx::tile_kernel", "layout": layout,
+                "kernel": ("dpx::span_kernel" if layout["walk_launches"] and not ((it, ot) == ("f32", "i16") and layout.get("f32_i16_by_tiles"))
+                           else "dpx::tile_kernel"), "layout": layout,
                 "avg_launch_ms": round(kms, 4), "algorithmic_bytes_per_launch": n * (bi + bo)}
         if prof and prof.get("avg_launch_us_kernel_trace"):
             roof["frac_rocprof"] = round(n * (bi + bo) / (prof["avg_launch_us_kernel_trace"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)

@@ -33,7 +33,8 @@ class Layout(C.Structure):
                 ("tile_samples", C.c_uint64), ("single_samples", C.c_uint64), ("table_entries", C.c_uint64),
                 ("n_stretches", C.c_uint32), ("rows_launches", C.c_uint32), ("tile_launches", C.c_uint32),
                 ("walk_launches", C.c_uint32), ("walk_matrices", C.c_uint32), ("walk_workgroups", C.c_uint32),
-                ("leftover_ranges", C.c_uint32), ("leftover_workgroups", C.c_uint32)]
+                ("leftover_ranges", C.c_uint32), ("leftover_workgroups", C.c_uint32),
+                ("f32_i16_by_tiles", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class StreamStats(C.Structure):

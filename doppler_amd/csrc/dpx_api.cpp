@@ -268,7 +268,7 @@ int run_plan(const dpx::PlanResult &plan, const DevPlan &dev, const void *d_in, 
         g.vecs = wide ? 1 : in_fmt == DPX_FMT_I16 ? 4 : 2;
     }
     if (g.block == 64 && !(in_fmt == DPX_FMT_I16 && out_fmt == DPX_FMT_I16)) { g.block = 128; g.vecs = 2; }   // 64 x 4 exists for i16 -> i16 only
-    for (const dpx::Launch &ln : plan.launches) {
+    for (const dpx::Launch &ln : dpx::launches_for(plan, in_fmt, out_fmt)) {
         int rc;
         if (ln.kind == 0)
             rc = dpx::launch_rows(d_in, in_fmt, d_out, out_fmt, dev.segs, dev.lut, ln.rows, fma, g.legacy_cast, st);
@@ -1062,6 +1062,7 @@ int dpx_plan_layout(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
     out->n_samples = plan.n_samples;
     out->n_stretches = (uint32_t)plan.segs.size();
     out->table_entries = plan.lut_entries;
+    out->f32_i16_by_tiles = plan.whole_tiles.empty() ? 0u : 1u;
     for (const dpx::Launch &ln : plan.launches) {
         if (ln.kind == 0) {
             ++out->rows_launches;

@@ -472,6 +472,11 @@ uint64_t walk_workgroups(const WalkSeg &w, const PlanTuning &tn)
 // Many matrices (track mode).  The descriptors fix the spans, not the workgroup size: f32 -> i16 (two 16-byte loads per
 // lane per row) runs its replays 1.5-2 points faster under 8 wavefronts (78.4 against 76.4 %, this round); the other pairs
 // lose under more than 4 (i16 -> f32 74.6 -> 72.6).  The planner's window shifts divide 4, hence 8.
+const std::vector<Launch> &launches_for(const PlanResult &plan, int in_fmt, int out_fmt)
+{
+    return (in_fmt == 1 && out_fmt == 0 && !plan.whole_tiles.empty()) ? plan.whole_tiles : plan.launches;
+}
+
 bool span_launch_shape(const WalkArgs &w, int in_fmt, int out_fmt, SpanLaunch *o)
 {
     const bool in_f32 = in_fmt == 1, out_f32 = out_fmt == 1;
@@ -503,6 +508,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
     plan.error = nullptr;
     plan.tables.clear();
     plan.launches.clear();
+    plan.whole_tiles.clear();
     plan.walk.clear();
     plan.walk_hint.clear();
     plan.left.clear();
@@ -809,6 +815,21 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         pos = std::max(pos, c.hi);
     }
     add_tiles(pos, plan.n_samples);
+    // launches_for(): the alternative of a many-matrix plan for f32 -> i16
+    if (choice == kChooseAuto && plan.n_samples != 0) {
+        bool many = false;
+        for (const Launch &ln : plan.launches) many = many || (ln.kind == 2 && ln.walk.uni.n_spans == 0);
+        if (many) {
+            Launch ln;
+            memset(&ln, 0, sizeof ln);
+            ln.kind = 1;
+            ln.tiles.m0 = 0;
+            ln.tiles.m1 = plan.n_samples;
+            ln.tiles.tile_lo = 0;
+            ln.tiles.n_tiles = (plan.n_samples + tile - 1) / tile;
+            plan.whole_tiles.push_back(ln);
+        }
+    }
 
     // ---- tile-kernel tables: every tabulated stretch with at least a tile's worth of samples in a tile launch
     const DevSeg *prev = nullptr;   // same (ratio, period) shares a table
@@ -865,7 +886,7 @@ void simulate(const PlanResult &plan, uint32_t *n_out, uint8_t *writes, int in_f
         while (si + 1 < ns && plan.segs[si].first + plan.segs[si].count <= g) ++si;
         put(g, counter_at(plan.segs[si], g - plan.segs[si].first));
     };
-    for (const Launch &ln : plan.launches) {
+    for (const Launch &ln : launches_for(plan, in_fmt, out_fmt)) {
         if (ln.kind == 0) {
             const RowsArgs &r = ln.rows;
             const DevSeg &s = plan.segs[0];

@@ -81,6 +81,9 @@ struct PlanResult {
     std::vector<uint32_t> hint;      // stretch index per 2^kHintShift samples
     std::vector<TableBuild> tables;
     std::vector<Launch> launches;
+    // f32 -> i16 only: ONE tile launch over the whole stream, filled when `launches` holds a span launch of many matrices
+    // (track mode) and the kernel choice is the planner's own — see launches_for()
+    std::vector<Launch> whole_tiles;
     // span-kernel launch (at most one per plan), each list closed by a sentinel
     std::vector<WalkSeg> walk;
     std::vector<uint32_t> walk_hint;  // WalkSeg index per 2^kWalkHintShift workgroups
@@ -105,6 +108,15 @@ void plan_append(PlanResult &plan, float ratio, uint64_t count, uint32_t &sample
 // after the last plan_append: choose the kernel for every stretch, lay out the
 // corrector tables, build the hint table and the launch list.
 void finalize(PlanResult &plan, uint32_t tile, int choice /* KernelChoice */, const PlanTuning &tuning = PlanTuning());
+
+// The launches of a finalized plan for one format pair (DPX_FMT_*: 0 = i16, 1 = f32): `plan.launches`, except that a
+// plan of many matrices (one span launch driven by descriptors: track mode) runs f32 -> i16 through the tile kernel alone,
+// every corrector evaluated per sample.  With 12 bytes per sample that arithmetic hides behind the memory side, and the
+// tile kernel's one-shot kilobyte tiles in address order stream better than eight-wavefront spans whose rows change lanes
+// through LDS: 300 s replay 79.6-80.4 % against 75.8-78.1 % of the HBM peak on four boxes of five (-1.3 on the fifth;
+// profiles/r04_walk.md section 5).  The other pairs, and one-matrix launches of this pair, tie or prefer the span kernel.
+// dpx_run_device and simulate() both take their launches from here.
+const std::vector<Launch> &launches_for(const PlanResult &plan, int in_fmt, int out_fmt);
 
 // Host mirror of the kernels' index arithmetic (no arithmetic on samples): for every
 // sample of a finalized plan, the counter value the launches would use, and how many

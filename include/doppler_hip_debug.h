@@ -78,6 +78,9 @@ typedef struct dpx_layout {
     uint32_t n_stretches;
     uint32_t rows_launches, tile_launches, walk_launches;
     uint32_t walk_matrices, walk_workgroups, leftover_ranges, leftover_workgroups;
+    uint32_t f32_i16_by_tiles;  /* 1: an f32 -> i16 run of this plan is ONE tile-kernel launch over the whole stream instead of
+                                 * the launches counted above (plans of many matrices: csrc/dpx_planner.h, launches_for) */
+    uint32_t reserved;
 } dpx_layout;
 int dpx_plan_layout(const dpx_segment *segs, size_t n_segs, uint32_t samplerate, uint32_t samplenum0,
                     int block, int vecs, int variant, const struct dpx_options *opt, dpx_layout *out);

@@ -155,6 +155,9 @@ def test_span_kernel_plans(orc):
         if i < 3:    # these really are span-kernel plans: matrices, leftover ranges, and (first plan) tile launches
             assert lay["walk_launches"] == 1 and lay["walk_matrices"] >= 8 and lay["leftover_ranges"] > 0, lay
             assert lay["rows_launches"] == 0, lay      # many tabulated stretches: never a rows plan, whatever their geometry
+            # such a plan runs f32 -> i16 as ONE tile launch over the stream (launches_for): the simulation below walks that
+            # for the pair under variant 3, and the span launch under variant 5 (the planner's choice overridden)
+            assert lay["f32_i16_by_tiles"] == 1 and doppler_amd.plan_layout(segs, rate, sn0, 128, 2, 5)["f32_i16_by_tiles"] == 0, lay
         for variant in (3, 5):
             for pair in PAIRS:
                 c, w = doppler_amd.plan_simulate(segs, rate, sn0, 128, 2, variant, pair=pair)

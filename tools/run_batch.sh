@@ -1,3 +1,4 @@
 set -u
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "tile_kernel_random or const_stream_bulk or per_sample" > gpurun_out/r04b_parity.log 2>&1; echo "parity rc=$?" ; tail -5 gpurun_out/r04b_parity.log
+timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/r04_final_gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -3 gpurun_out/r04_final_gpu_tests.log
+ONLY='replay 300' SUFFIX=_route timeout 900 tools/table_rocprof.sh > /dev/null 2>&1; cat gpurun_out/r04_table_rocprof_route.md

@@ -76,6 +76,7 @@ row "per sample: track replay 300 s, f32->i16" 12 track300f pair=f32:i16 variant
 row "per sample: track replay 300 s, f32->f32" 16 track300f pair=f32:f32 variant=1
 row "per sample: track replay 300 s, i16->f32" 12 track300f pair=i16:f32 variant=1
 row "per sample: track replay 600 s, i16->i16" 8 track600 variant=1
+row "span kernel forced (variant 5): track replay 300 s, f32->i16" 12 track300f pair=f32:i16 variant=5
 row "span: 5001 Hz, f32->i16" 12 const5001 pair=f32:i16
 row "span: 5001 Hz, i16->f32" 12 const5001 pair=i16:f32
 cat $OUTMD
