@@ -1,4 +1,8 @@
 set -u
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/r04_final_gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -3 gpurun_out/r04_final_gpu_tests.log
-ONLY='replay 300' SUFFIX=_route timeout 900 tools/table_rocprof.sh > /dev/null 2>&1; cat gpurun_out/r04_table_rocprof_route.md
+for i in 1 2 3; do
+timeout 900 python bench.py > gpurun_out/r04_bench_line_run$i.json 2> gpurun_out/r04_bench_stderr.log; echo "bench rc=$?"
+python -c "
+import json; b=json.loads(open('gpurun_out/r04_bench_line_run$i.json').read()); print(b['value'], b['roofline']['frac'], b['roofline']['traffic'], b['roofline'].get('frac_rocprof'), b['extra']['track']['roofline']['frac'], b['extra']['track']['roofline'].get('frac_rocprof'), b['per_rank'][0]['pci_bus_id'])"
+done
+rocm-smi --showpower --showtemp --showclocks 2>/dev/null | head -30
