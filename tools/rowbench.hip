@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64) void tall(const uint8_t *__restrict__ in, uint8
 
 // WAVES wavefronts x U rows per workgroup with a barrier between the loads and the stores (today's walk kernel);
 // rows_in_chunk <= WAVES * U: wavefronts past it leave at once
-template <int WAVES, int U>
+template <int WAVES, int U, bool BAR = true>
 __global__ __launch_bounds__(WAVES * 64) void wgk(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint64_t Lb,
                                                   int rows_in_chunk, int work_fix, int work_row, float k)
 {
@@ -83,10 +83,14 @@ __global__ __launch_bounds__(WAVES * 64) void wgk(const uint8_t *__restrict__ in
         const bool valid = r0 + u < rows_in_chunk;
         q[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in + (valid ? base + (uint64_t)u * Lb : (uint64_t)lane * 16u)));
     }
-    if (work_fix) sl[threadIdx.x] = fix_work(work_fix, (double)threadIdx.x);
-    __syncthreads();
     uint32_t x = 0;
-    if (work_fix) x = (uint32_t)(sl[threadIdx.x ^ 1u] > 1e300);
+    if constexpr (BAR) {
+        if (work_fix) sl[threadIdx.x] = fix_work(work_fix, (double)threadIdx.x);
+        __syncthreads();
+        if (work_fix) x = (uint32_t)(sl[threadIdx.x ^ 1u] > 1e300);
+    } else {      // the same workgroup without its barrier (round 4: is it the grouping or the barrier that costs?)
+        if (work_fix) x = (uint32_t)(fix_work(work_fix, (double)threadIdx.x) > 1e300);
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (r0 + u >= rows_in_chunk) break;
@@ -111,7 +115,12 @@ static uint8_t *g_in, *g_out;
 static uint64_t g_n;
 
 template <int R> static void launch_tall(const Case &c, dim3 grid) { tall<R><<<grid, 64>>>(g_in, g_out, c.Lb, c.work_fix, c.work_row, 0.999f); }
-template <int W, int U> static void launch_wg(const Case &c, dim3 grid) { wgk<W, U><<<grid, W * 64>>>(g_in, g_out, c.Lb, c.R, c.work_fix, c.work_row, 0.999f); }
+static bool g_nobar = false;
+template <int W, int U> static void launch_wg(const Case &c, dim3 grid)
+{
+    if (g_nobar) wgk<W, U, false><<<grid, W * 64>>>(g_in, g_out, c.Lb, c.R, c.work_fix, c.work_row, 0.999f);
+    else         wgk<W, U, true><<<grid, W * 64>>>(g_in, g_out, c.Lb, c.R, c.work_fix, c.work_row, 0.999f);
+}
 
 static bool launch(Case &c)
 {
@@ -127,6 +136,7 @@ static bool launch(Case &c)
             default: return false;
         }
     } else {
+        g_nobar = c.name.find("nobar") != std::string::npos;
 #define W(WW, UU) if (c.waves == WW && c.U == UU) { launch_wg<WW, UU>(c, grid); return true; }
         W(4, 2) W(5, 2) W(8, 2) W(3, 3) W(4, 3) W(2, 4) W(2, 5) W(2, 6) W(2, 8) W(3, 4) W(4, 4)
 #undef W
@@ -212,6 +222,22 @@ int main(int argc, char **argv)
             add("D", Lb, 8, 4, 2, 50, 48);
             add("D", Lb, 9, 5, 2, 40, 48);
             add("D", Lb, 5, 4, 2, 50, 48);
+        }
+    }
+    if (!strcmp(set, "group")) {
+        // H (round 4): what costs a 4-wavefront workgroup 4 points against four one-wavefront workgroups — the grouping or
+        // the barrier?  Same windows, same rows (441 KiB and 32 KiB apart), with and without the barrier.
+        for (uint64_t Lb : {441 * K, 32 * K}) {
+            add("H", Lb, 2, 0, 0, 0, 0);
+            add("H", Lb, 8, 0, 0, 0, 0);
+            add("H", Lb, 8, 4, 2, 0, 0);
+            add("H nobar", Lb, 8, 4, 2, 0, 0);
+            add("H", Lb, 4, 2, 4, 0, 0);         // (2 wavefronts: rows_in_chunk 4 = 2 x 2)
+            add("H", Lb, 16, 8, 2, 0, 0);
+            add("H nobar", Lb, 16, 8, 2, 0, 0);
+            add("H", Lb, 8, 4, 2, 50, 48);
+            add("H nobar", Lb, 8, 4, 2, 50, 48);
+            add("H", Lb, 2, 0, 0, 200, 48);
         }
     }
     if (!strcmp(set, "pitch")) {
