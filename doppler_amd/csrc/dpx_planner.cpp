@@ -352,7 +352,7 @@ struct WalkShape { uint32_t waves, span; bool fixed; };
 WalkShape walk_shape(const PlanTuning &tn)
 {
     WalkShape g = {kSpanWaves, kSpanRows, false};
-    if (tn.walk_waves == 2 || tn.walk_waves == 4 || tn.walk_waves == 5 || tn.walk_waves == 8) g.waves = tn.walk_waves;
+    if (tn.walk_waves != 0 && walk_waves_ok(tn.walk_waves, false)) g.waves = tn.walk_waves;
     if (tn.walk_span >= 2) { g.span = tn.walk_span; g.fixed = true; }
     return g;
 }
@@ -472,6 +472,11 @@ uint64_t walk_workgroups(const WalkSeg &w, const PlanTuning &tn)
 // Many matrices (track mode).  The descriptors fix the spans, not the workgroup size: f32 -> i16 (two 16-byte loads per
 // lane per row) runs its replays 1.5-2 points faster under 8 wavefronts (78.4 against 76.4 %, this round); the other pairs
 // lose under more than 4 (i16 -> f32 74.6 -> 72.6).  The planner's window shifts divide 4, hence 8.
+bool walk_waves_ok(uint32_t waves, bool uni)
+{
+    return waves == 2 || waves == 4 || waves == 5 || (waves == 8 && !uni);
+}
+
 const std::vector<Launch> &launches_for(const PlanResult &plan, int in_fmt, int out_fmt)
 {
     return (in_fmt == 1 && out_fmt == 0 && !plan.whole_tiles.empty()) ? plan.whole_tiles : plan.launches;
@@ -498,7 +503,7 @@ bool span_launch_shape(const WalkArgs &w, int in_fmt, int out_fmt, SpanLaunch *o
     }
     if (!uni && w.auto_shape && in_f32 && !out_f32) o->waves = 8;
     if (uni && (uint64_t)o->uni.n_spans + o->left_rows > 65535u) return false;
-    return o->waves == 2 || o->waves == 4 || o->waves == 5 || (o->waves == 8 && !uni);
+    return walk_waves_ok(o->waves, uni);
 }
 
 void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)

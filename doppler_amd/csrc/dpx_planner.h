@@ -109,6 +109,9 @@ void plan_append(PlanResult &plan, float ratio, uint64_t count, uint32_t &sample
 // corrector tables, build the hint table and the launch list.
 void finalize(PlanResult &plan, uint32_t tile, int choice /* KernelChoice */, const PlanTuning &tuning = PlanTuning());
 
+// wavefronts per workgroup the span kernel is built for (PlanTuning::walk_waves, SpanLaunch::waves)
+bool walk_waves_ok(uint32_t waves, bool uni);
+
 // The launches of a finalized plan for one format pair (DPX_FMT_*: 0 = i16, 1 = f32): `plan.launches`, except that a
 // plan of many matrices (one span launch driven by descriptors: track mode) runs f32 -> i16 through the tile kernel alone,
 // every corrector evaluated per sample.  With 12 bytes per sample that arithmetic hides behind the memory side, and the

@@ -370,6 +370,11 @@ def cases(which):
             c.append(("track 300 s replay", lambda f: track_segs(300, f), pair, 3, dict(_geom=(0, 0))))
             for waves, span in shapes:
                 c.append(("track 300 s replay", lambda f: track_segs(300, f), pair, 3, dict(_geom=(0, 0), walk_waves=waves, walk_span=span)))
+    if which == "w1":            # i16 -> f32 under one-wavefront span workgroups (needed a build with a WAVES = 1 instantiation: round 4, dropped)
+        for name, fn in (("track 300 s replay", lambda f: track_segs(300, f)), ("const 5001 Hz", lambda f: const_segs(5001))):
+            c.append((name, fn, "i16:f32", 3, dict(_geom=(0, 0))))
+            for waves, span in ((1, 2), (1, 4), (1, 3), (2, 4), (2, 2)):
+                c.append((name, fn, "i16:f32", 3, dict(_geom=(0, 0), walk_waves=waves, walk_span=span)))
     if which == "route3":        # pairs with an f32 side: the default plan (span kernel) against every corrector per sample (tile kernel)
         for pair in ("f32:i16", "i16:f32", "f32:f32"):
             for variant in (3, 1):
@@ -394,7 +399,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
     ap.add_argument("--shuffle", action="store_true", help="time the cases in a different order every round")
-    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3", "pairs", "pairs2", "rowrule", "pairs3", "shapes", "pairs4", "tshape", "longp", "route2", "sincos1", "persample4", "route3", "pairshape"])
+    ap.add_argument("--set", default="all", choices=["all", "walk", "const", "persample", "synth", "size", "shape", "hybrid", "final", "route", "f32", "t600", "merge", "rowsopt", "waves", "bigp", "geom", "bigshape", "rcomp", "rthresh", "rowlen", "rowlen2", "synth2", "span", "span2", "exp1", "uni", "pack", "minl", "policy", "reg1", "span3", "pairs", "pairs2", "rowrule", "pairs3", "shapes", "pairs4", "tshape", "longp", "route2", "sincos1", "persample4", "route3", "pairshape", "w1"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = doppler_amd.Context(0)
