@@ -11,7 +11,8 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-f
             -Wall -Wno-unused-function -Iinclude
 
 LIB := $(LIBDIR)/libdoppler_hip.so
-OBJS := $(LIBDIR)/dpx_kernels.o $(LIBDIR)/dpx_api.o $(LIBDIR)/dpx_planner.o $(LIBDIR)/orbit.o $(LIBDIR)/schedule.o
+API  := dpx_context dpx_resident dpx_operators dpx_plans dpx_stream
+OBJS := $(LIBDIR)/dpx_kernels.o $(API:%=$(LIBDIR)/%.o) $(LIBDIR)/dpx_planner.o $(LIBDIR)/orbit.o $(LIBDIR)/schedule.o
 
 all: lib cli oracle cpptest
 
@@ -23,7 +24,8 @@ $(LIBDIR)/dpx_kernels.o: $(CSRC)/dpx_kernels.hip $(CSRC)/dpx_sincos.h $(CSRC)/dp
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -mllvm -amdgpu-kernarg-preload-count=16 -c $< -o $@
 
-$(LIBDIR)/dpx_api.o: $(CSRC)/dpx_api.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h $(CSRC)/host/orbit.h $(CSRC)/host/schedule.h include/doppler_hip.h include/doppler_hip_debug.h include/doppler_hip_host.h
+# the C ABI: host C++ over the HIP runtime API (no device code)
+$(API:%=$(LIBDIR)/%.o): $(LIBDIR)/%.o: $(CSRC)/%.cpp $(CSRC)/dpx_internal.h $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h $(CSRC)/host/orbit.h $(CSRC)/host/schedule.h include/doppler_hip.h include/doppler_hip_debug.h include/doppler_hip_host.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 

@@ -42,9 +42,14 @@ class StreamStats(C.Structure):
                 ("enqueue_us", C.c_double), ("total_us", C.c_double)]
 
 
+class ResidentCounters(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("blocks", C.c_uint64), ("stops", C.c_uint64), ("idle_exits", C.c_uint64),
+                ("running", C.c_uint32), ("tickets_in_flight", C.c_uint32), ("slots_parked", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class Options(C.Structure):
     _fields_ = [("rows_mult", C.c_uint32), ("rows_maxl", C.c_uint32), ("rows_r", C.c_uint32), ("rows_compute", C.c_uint32),
-                ("walk_waves", C.c_uint32), ("walk_span", C.c_uint32), ("walk_flags", C.c_uint32), ("reserved", C.c_uint32),
+                ("walk_waves", C.c_uint32), ("walk_span", C.c_uint32), ("walk_flags", C.c_uint32), ("sub_lg", C.c_uint32),
                 ("walk_tilemin", C.c_uint64)]
 
 
@@ -104,6 +109,7 @@ _SIGNATURES = {
     "dpx_plan_n_samples": (_i, [_vp, _P(_u64)]),
     "dpx_set_resident": (_i, [_vp, _i]),
     "dpx_resident_stats": (_i, [_vp, _P(_u64), _P(_u64)]),
+    "dpx_resident_info": (_i, [_vp, _vp]),
     "dpx_plan_final_samplenum": (_i, [_vp, _P(_u32)]),
     "dpx_plan_destroy": (None, [_vp]),
     "dpx_stream_create": (_i, [_vp, _i, _i, _u32, _u32, _sz, _i, _P(_vp)]),

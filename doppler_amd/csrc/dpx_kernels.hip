@@ -1002,6 +1002,7 @@ __global__ __launch_bounds__(WAVES * 64) void span_kernel(const uint8_t *__restr
                                                             const WalkSeg *__restrict__ wdesc,     // !UNI only
                                                             uint32_t n_left_wg,
                                                             uint32_t cast_legacy,                  // dpx_set_i16_cast
+                                                            uint32_t wg_off,                       // sub-launch: first span (UNI: grid row) / first workgroup of this launch
                                                             // ---- leftover path only
                                                             const LeftRange *__restrict__ left,
                                                             const uint32_t *__restrict__ lhint,
@@ -1021,7 +1022,7 @@ __global__ __launch_bounds__(WAVES * 64) void span_kernel(const uint8_t *__restr
     const uint32_t half = blockIdx.x % kSplit;
     const bool legacy = cast_legacy != 0;                         // uniform
     if constexpr (UNI) {
-        const uint32_t w = blockIdx.x / kSplit, c = blockIdx.y;
+        const uint32_t w = blockIdx.x / kSplit, c = blockIdx.y + wg_off;
         if (c < uni.n_spans) {
             if (w >= uni.seg.nw) return;                          // padding
             WalkSeg ws = uni.seg;
@@ -1039,7 +1040,7 @@ __global__ __launch_bounds__(WAVES * 64) void span_kernel(const uint8_t *__restr
         // (replicated per group; spans start on multiples of 8 workgroups) or a group of leftover blocks.  The leftover
         // groups (sincos per sample, VALU-bound) are spread evenly between the spans by the planner, so that they run
         // beside memory-bound workgroups.
-        const uint32_t b = blockIdx.x / kSplit;
+        const uint32_t b = blockIdx.x / kSplit + wg_off;
         const WalkSeg ws = wdesc[b >> kWalkHintShift];
         const uint32_t w = b - ws.wg_base;
         if (w >= ws.nwg) return;                                  // padding
@@ -1075,12 +1076,19 @@ __global__ __launch_bounds__(kResidentThreads) void resident_block_kernel(Reside
     __syncthreads();
     for (;;) {
         if (tid == 0) {
-            // doorbell, sample count, stretch count and cast mode are the first 16 bytes of the host-written line: ONE PCIe
-            // read (the host stores the doorbell last, with release semantics; an aligned 16-byte read sees one state of the line)
+            // ticket, payload (sample count, stretch count, cast mode, kernel instance) and the ticket again are the first 16
+            // bytes of the host-written line: ONE PCIe read.  The word proves itself (dpx_types.h, ctl_word_valid): a read
+            // that caught the line between two of the host's stores is taken as "not rung yet".
             const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(ctl));
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
-            const uint32_t d = w[0];
+            const uint32_t d = ctl_word_valid(w[0], w[1], w[3]) ? w[0] : last;
             uint32_t leave = d == kDoorExit ? 1u : 0u;
+            if (d != last && d != kDoorExit && ((w[1] >> 20) & 7u) != ctl_instance(IN_FMT, OUT_FMT, FMA)) {
+                // a ticket rung for another instance of this kernel (format pair, libm build): not ours to serve — everyone
+                // leaves, the host starts the right kernel and that one finds the doorbell rung (dpx_resident.cpp)
+                __hip_atomic_store(&ra.shared->leaving, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                leave = 1;
+            }
             if (d == last) {                                      // (a block that has been rung is always finished first)
                 if (__hip_atomic_load(&ra.shared->leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                     leave = 1;
@@ -1095,9 +1103,9 @@ __global__ __launch_bounds__(kResidentThreads) void resident_block_kernel(Reside
             }
             s_door = d;
             s_leave = leave;
-            s_n = w[1];
-            s_nsegs = w[2];
-            s_legacy = w[3];
+            s_n = w[1] & 0x3fffu;
+            s_nsegs = (w[1] >> 14) & 0x1fu;
+            s_legacy = (w[1] >> 19) & 1u;
         }
         __syncthreads();
         const uint32_t d = s_door, leave = s_leave, n = s_n, n_segs = s_nsegs;
@@ -1260,19 +1268,29 @@ static int tiles_t(const void *d_in, void *d_out, const DevSeg *d_segs, uint32_t
     const float2 *lut = static_cast<const float2 *>(d_lut);
     if (t.n_tiles == 0) return DPX_OK;
     if (t.n_tiles > 0x7fffffffull) return DPX_ERR_ARG;
-    const dim3 grid((uint32_t)t.n_tiles);
+    // sub-launches of about 2^sub_lg samples each (see span_t): a tile launch is cut by tile index on the host
+    const uint64_t n_all = t.n_tiles, lo_all = t.tile_lo;
+    const uint32_t pieces = sub_launch_pieces(n_all * g.tile(), g.sub_lg);
+    const uint64_t per = (n_all + pieces - 1) / pieces;
+    for (uint64_t off = 0; off < n_all; off += per) {
+        t.tile_lo = lo_all + off;
+        t.n_tiles = n_all - off < per ? n_all - off : per;
+        const dim3 grid((uint32_t)t.n_tiles);
 #define DPX_CASE(B, Vv)                                                                                      \
-    if (g.block == B && g.vecs == Vv) {                                                                      \
-        if (fma) tile_kernel<IN_FMT, OUT_FMT, true, B, Vv><<<grid, B, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t);  \
-        else     tile_kernel<IN_FMT, OUT_FMT, false, B, Vv><<<grid, B, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t); \
-        return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                       \
-    }
-    DPX_CASE(128, 2) DPX_CASE(256, 1)
-    if constexpr (IN_FMT == DPX_FMT_I16 && OUT_FMT == DPX_FMT_I16) {       // one wavefront x 16 samples per lane: built for this pair only
-        DPX_CASE(64, 4)
-    }
+        if (g.block == B && g.vecs == Vv) {                                                                  \
+            if (fma) tile_kernel<IN_FMT, OUT_FMT, true, B, Vv><<<grid, B, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t);  \
+            else     tile_kernel<IN_FMT, OUT_FMT, false, B, Vv><<<grid, B, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t); \
+            if (hipGetLastError() != hipSuccess) return DPX_ERR_HIP;                                         \
+            continue;                                                                                        \
+        }
+        DPX_CASE(128, 2) DPX_CASE(256, 1)
+        if constexpr (IN_FMT == DPX_FMT_I16 && OUT_FMT == DPX_FMT_I16) {       // one wavefront x 16 samples per lane: built for this pair only
+            DPX_CASE(64, 4)
+        }
 #undef DPX_CASE
-    return DPX_ERR_ARG;
+        return DPX_ERR_ARG;
+    }
+    return DPX_OK;
 }
 
 int launch_tiles(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,
@@ -1324,6 +1342,12 @@ int launch_rows(const void *d_in, int in_fmt, void *d_out, int out_fmt, const De
     DPX_DISPATCH_FMT(rows_t, d_in, d_out, d_segs, d_lut, r, fma, legacy_cast, st);
 }
 
+// Sub-launches.  One launch over a stream of 4 GiB runs 2-3 points below the same launch cut into pieces of 1 GiB — span
+// kernel, const 5001 Hz, one box: 75.6 % whole against 78.8 % as four launches back to back (79.9-78.5 each alone); 8 GiB:
+// 77.7 against 80.7 (profiles/r05_generality.md; the rows kernel shows nothing of the kind: 84.7 whole, 83.4 cut).  The
+// counters name no cause (same requests, fewer DRAM-credit stalls, address translation misses 0.02 per thousand samples in
+// both), so the remedy is the measured one: the grid is dealt out in pieces that cover about 2^sub_lg samples each, back to
+// back on the stream.  Workgroups are independent and find their work from (wg_off + blockIdx), so a cut anywhere is valid.
 template <int IN_FMT, int OUT_FMT>
 static int span_t(const void *d_in, void *d_out, const DevSeg *d_segs, const WalkSeg *d_wdesc,
                   const LeftRange *d_left, const uint32_t *d_lhint, const WalkArgs &w, bool fma, int legacy_cast, hipStream_t st)
@@ -1336,22 +1360,32 @@ static int span_t(const void *d_in, void *d_out, const DevSeg *d_segs, const Wal
     const uint64_t n_wg = (uint64_t)w.n_walk_wg * kSplit;
     if (n_wg == 0) return DPX_OK;
     if (n_wg > 0x7fffffffull || w.span == 0) return DPX_ERR_ARG;
-    const dim3 grid((uint32_t)n_wg);
     // what this format pair makes of the plan's shape (dpx_planner.cpp: the same function the planner's simulation walks)
     SpanLaunch sl;
     if (!span_launch_shape(w, IN_FMT, OUT_FMT, &sl)) return DPX_ERR_ARG;
     const bool uni = sl.uni.n_spans != 0;
-    const dim3 ugrid(uni ? sl.uni.nw8 * kSplit : 1, uni ? sl.uni.n_spans + sl.left_rows : 1);
+    // pieces: grid rows (one matrix: a row is a span or a row of leftover blocks) or workgroups (multiples of 8: descriptor groups)
+    const uint32_t units = uni ? sl.uni.n_spans + sl.left_rows : w.n_walk_wg;
+    const uint32_t pieces = sub_launch_pieces(w.cover, w.sub_lg);
+    uint32_t per = (units + pieces - 1) / pieces;
+    if (!uni) per = (per + 7u) & ~7u;
+    if (per == 0) per = units;
+    for (uint32_t off = 0; off < units; off += per) {
+        const uint32_t cnt = units - off < per ? units - off : per;
+        const dim3 grid = uni ? dim3(sl.uni.nw8 * kSplit, cnt) : dim3(cnt * kSplit);
 #define DPX_SPAN_CASE(WW, UU)                                                                                                          \
-    if (sl.waves == WW && uni == UU) {                                                                                                 \
-        if (fma) span_kernel<IN_FMT, OUT_FMT, true, WW, UU><<<UU ? ugrid : grid, WW * 64, 0, st>>>(in, out, sl.uni, d_wdesc, w.n_left_wg, lg, d_left, d_lhint, d_segs);   \
-        else     span_kernel<IN_FMT, OUT_FMT, false, WW, UU><<<UU ? ugrid : grid, WW * 64, 0, st>>>(in, out, sl.uni, d_wdesc, w.n_left_wg, lg, d_left, d_lhint, d_segs);  \
-        return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                                                 \
-    }
-    DPX_SPAN_CASE(4, true) DPX_SPAN_CASE(4, false) DPX_SPAN_CASE(5, true) DPX_SPAN_CASE(2, true) DPX_SPAN_CASE(8, false)
-    DPX_SPAN_CASE(5, false) DPX_SPAN_CASE(2, false)
+        if (sl.waves == WW && uni == UU) {                                                                                             \
+            if (fma) span_kernel<IN_FMT, OUT_FMT, true, WW, UU><<<grid, WW * 64, 0, st>>>(in, out, sl.uni, d_wdesc, w.n_left_wg, lg, off, d_left, d_lhint, d_segs);   \
+            else     span_kernel<IN_FMT, OUT_FMT, false, WW, UU><<<grid, WW * 64, 0, st>>>(in, out, sl.uni, d_wdesc, w.n_left_wg, lg, off, d_left, d_lhint, d_segs);  \
+            if (hipGetLastError() != hipSuccess) return DPX_ERR_HIP;                                                                   \
+            continue;                                                                                                                  \
+        }
+        DPX_SPAN_CASE(4, true) DPX_SPAN_CASE(4, false) DPX_SPAN_CASE(5, true) DPX_SPAN_CASE(2, true) DPX_SPAN_CASE(8, false)
+        DPX_SPAN_CASE(5, false) DPX_SPAN_CASE(2, false)
 #undef DPX_SPAN_CASE
-    return DPX_ERR_ARG;
+        return DPX_ERR_ARG;
+    }
+    return DPX_OK;
 }
 
 int launch_span(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,

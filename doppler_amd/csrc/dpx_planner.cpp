@@ -510,6 +510,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
 {
     const uint64_t kWalkTileMin = tn.walk_tilemin ? tn.walk_tilemin : kWalkTileMinDefault;
     plan.tile = tile;
+    plan.sub_lg = tn.sub_lg;
     plan.error = nullptr;
     plan.tables.clear();
     plan.launches.clear();
@@ -762,6 +763,10 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         ln.walk.span = shape.span;
         memset(&ln.walk.uni, 0, sizeof ln.walk.uni);
         ln.walk.auto_shape = (!tn.walk_waves && !tn.walk_span) ? 1u : 0u;
+        ln.walk.sub_lg = tn.sub_lg;
+        ln.walk.cover = 0;
+        for (const WalkSeg &m : mats) ln.walk.cover += m.E - m.A;
+        for (const LeftRange &lr : plan.left) ln.walk.cover += lr.len;
         // one matrix: the kernel takes it from its arguments (no such kernel is built for 8 wavefronts: no pair's cut wants them)
         if (mats.size() == 1 && plain_spans && !(tn.walk_flags & 1u) && shape.waves != 8) {
             const uint32_t k = walk_chunks(mats[0], tnw);

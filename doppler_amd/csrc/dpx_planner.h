@@ -62,9 +62,11 @@ struct PlanTuning {
                                  // most that many rows, one window per workgroup, two rows per wavefront per turn
     uint32_t walk_flags = 0;     // bit 0: a one-matrix span launch reads descriptors like any other (measurement of what the
                                  // descriptor load costs); bits 8..: row-length target in KiSamples (measurement)
+    uint32_t sub_lg = 0;         // span and tile launches are dealt out in pieces of about 2^sub_lg samples (0 = kSubLaunchLg,
+                                 // >= 48 = never cut)
     bool operator==(const PlanTuning &o) const
     {
-        return rows_mult == o.rows_mult && rows_maxl == o.rows_maxl && rows_r == o.rows_r && walk_waves == o.walk_waves &&
+        return sub_lg == o.sub_lg && rows_mult == o.rows_mult && rows_maxl == o.rows_maxl && rows_r == o.rows_r && walk_waves == o.walk_waves &&
                rows_compute == o.rows_compute && walk_tilemin == o.walk_tilemin && walk_span == o.walk_span &&
                walk_flags == o.walk_flags;
     }
@@ -77,6 +79,7 @@ struct PlanResult {
     // filled by finalize():
     uint64_t lut_entries = 0;        // size of the corrector-table pool, in (cos, sin) entries
     uint32_t tile = 0;               // tile-kernel samples per workgroup the tables were laid out for
+    uint32_t sub_lg = 0;             // PlanTuning::sub_lg, for the tile launches (span launches carry it in WalkArgs)
     bool tile_tables = false;        // some stretch is served from a tile-kernel table
     std::vector<uint32_t> hint;      // stretch index per 2^kHintShift samples
     std::vector<TableBuild> tables;

@@ -1,0 +1,473 @@
+// dpx_stream.cpp — the slab ring: streaming from host memory, on one GPU or several
+// (one of the translation units behind include/doppler_hip*.h: see dpx_internal.h)
+#include <stdio.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <new>
+#include <string>
+#include <thread>
+
+#include "dpx_internal.h"
+
+using namespace dpx_api;
+
+// what a slab's resident plan was made from (dpx_stream_submit reuses plan and device image on a match)
+struct SlabKey {
+    uint64_t segs_hash = 0;
+    uint32_t samplerate = 0, sn_start = 0;
+    int variant = 0, choice = 0, fma = 0, cast = 0, block = 0, vecs = 0, autosel = 0;
+    dpx::PlanTuning tuning;
+    bool operator==(const SlabKey &o) const
+    {
+        return segs_hash == o.segs_hash && samplerate == o.samplerate && sn_start == o.sn_start && variant == o.variant &&
+               choice == o.choice && fma == o.fma && cast == o.cast && block == o.block && vecs == o.vecs && autosel == o.autosel &&
+               tuning == o.tuning;
+    }
+};
+
+static SlabKey slab_key(const dpx_ctx *ctx, const dpx::LaunchGeom &g, const dpx_segment *segs, size_t n_segs, uint32_t samplerate, uint32_t sn)
+{
+    SlabKey k;
+    uint64_t h = 1469598103934665603ull;                       // FNV-1a over the segments' fields (the list itself is compared as well)
+    for (size_t i = 0; i < n_segs; ++i) {
+        uint32_t bits;
+        memcpy(&bits, &segs[i].shift_hz, sizeof bits);
+        h = (h ^ segs[i].n_samples) * 1099511628211ull;
+        h = (h ^ bits) * 1099511628211ull;
+    }
+    k.segs_hash = h;
+    k.samplerate = samplerate;
+    k.sn_start = sn;
+    k.variant = ctx->variant;
+    k.choice = ctx->choice;
+    k.fma = ctx->fma;
+    k.cast = ctx->i16_cast;
+    k.block = g.block;
+    k.vecs = g.vecs;
+    k.autosel = g.autosel;
+    k.tuning = ctx->tuning;
+    return k;
+}
+
+struct dpx_stream_slab {
+    SlabKey key;
+    bool have_key = false;
+    std::vector<dpx_segment> key_segs;
+    uint32_t key_sn_after = 0;
+    dpx_ctx *ctx = nullptr;      // the GPU this slab is processed on (slab k of the ring belongs to context k mod n)
+    char *h_in = nullptr, *h_out = nullptr;
+    void *d_in = nullptr, *d_out = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    int numa_node = -1;          // where the pinned buffers were placed (-1: the caller's default policy)
+    // several GPUs: the device work of a slab is enqueued by its GPU's own thread (dpx_stream::Worker)
+    std::atomic<int> enq{0};     // 0: nothing pending; 1: handed to the worker; 2: enqueued (enq_rc says how it went)
+    int enq_rc = 0;
+    std::string enq_err;
+    size_t job_in_bytes = 0;
+    bool job_reuse = false;
+    dpx::LaunchGeom job_geom = {128, 2};
+    bool job_fma = true;
+    dpx::PlanResult plan;
+    DevPlan dev;
+    size_t out_bytes = 0;
+    std::atomic<int> state{0};   // 0 free, 1 acquired (being filled), 2 in flight, 3 handed out by next()
+    dpx_stream_slab() = default;
+    dpx_stream_slab(const dpx_stream_slab &) {}   // slabs are only ever default-constructed (vector::resize)
+};
+
+struct dpx_stream {
+    dpx_ctx *ctx = nullptr;      // first context: holds the period cache and the tuning all slabs are planned with
+    std::vector<dpx_ctx *> ctxs;
+    int in_fmt = 0, out_fmt = 0;
+    uint32_t samplerate = 0, samplenum = 0;
+    size_t slab_bytes = 0, slab_out = 0;
+    std::vector<dpx_stream_slab> slabs;
+    size_t acq = 0;     // next slab to acquire            (producer side: acquire, then submit in the same order)
+    size_t head = 0;    // oldest acquired slab, the next to submit
+    size_t tail = 0;    // oldest submitted slab not yet handed out   (consumer side: next)
+    size_t rel = 0;     // oldest handed-out slab                     (release, in the same order)
+    std::atomic<int> in_flight{0};
+    dpx_stream_stats stats = {};   // host cost of dpx_stream_submit, by part (dpx_stream_get_stats)
+    // Several GPUs: one enqueue thread per context.  dpx_stream_submit plans on the caller's thread (the counter is carried
+    // from slab to slab: sequential by nature, 0.1-1 us) and hands the device work — plan image, H2D, launch, D2H, event:
+    // 7-12 us of HIP calls — to the thread of the slab's GPU, so that eight GPUs are fed by eight threads, each running on
+    // the NUMA node of its GPU, and a slow call into one GPU's runtime does not hold up the others.
+    struct Worker {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<size_t> jobs;
+        bool stop = false;
+    };
+    std::vector<std::unique_ptr<Worker>> workers;
+    mutable std::mutex enq_mu;     // guards stats' upload / enqueue parts and wakes dpx_stream_next
+    std::condition_variable enq_cv;
+};
+
+namespace {
+void slab_worker(dpx_stream *s, dpx_stream::Worker *w, int numa_node);
+}
+
+namespace {
+
+// NUMA node of a GPU's PCIe root (sysfs, through the device's PCI bus id), or -1.  An 8-GPU MI355X node has two sockets,
+// four GPUs under each: a slab ring whose pinned buffers all come from the creating thread's node sends half of the
+// D2H traffic (8 x 25-28 GB/s at the kernel's rate) across the socket link.
+int gpu_numa_node(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) return -1;
+    for (char *c = bus; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    char path[128];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
+// Pinned allocations of the calling thread prefer `node` until the policy is reset (node < 0: the default policy).
+// set_mempolicy(2) by number: no libnuma in the image; failure (no NUMA, seccomp) is silent — the default policy stays.
+void prefer_numa_node(int node)
+{
+#ifdef SYS_set_mempolicy
+    constexpr int kMpolDefault = 0, kMpolPreferred = 1;
+    if (node < 0 || node >= 1024) {
+        (void)syscall(SYS_set_mempolicy, kMpolDefault, nullptr, 0);
+        return;
+    }
+    unsigned long mask[1024 / (8 * sizeof(unsigned long))] = {0};
+    mask[(size_t)node / (8 * sizeof(unsigned long))] |= 1ul << ((size_t)node % (8 * sizeof(unsigned long)));
+    (void)syscall(SYS_set_mempolicy, kMpolPreferred, mask, 1024 + 1);
+#else
+    (void)node;
+#endif
+}
+
+}  // namespace
+
+extern "C" {
+
+int dpx_stream_create_multi(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_fmt, uint32_t samplerate,
+                            uint32_t samplenum0, size_t slab_bytes, int slabs_per_ctx, dpx_stream **out)
+{
+    if (!ctxs || n_ctx < 1 || n_ctx > 64 || !out || !fmt_ok(in_fmt) || !fmt_ok(out_fmt) || slabs_per_ctx < 1 ||
+        (long)slabs_per_ctx * n_ctx > 256)
+        return fail(DPX_ERR_ARG, "bad argument");
+    for (int i = 0; i < n_ctx; ++i)
+        if (!ctxs[i]) return fail(DPX_ERR_ARG, "context %d is null", i);
+    *out = nullptr;
+    const size_t ibs = bytes_per_sample(in_fmt), obs = bytes_per_sample(out_fmt);
+    slab_bytes = slab_bytes / 16 * 16;
+    if (slab_bytes < 16) return fail(DPX_ERR_ARG, "slab_bytes must be at least 16");
+    dpx_stream *s = new (std::nothrow) dpx_stream;
+    if (!s) return fail(DPX_ERR_ARG, "out of host memory");
+    s->ctx = ctxs[0];
+    s->ctxs.assign(ctxs, ctxs + n_ctx);
+    s->in_fmt = in_fmt;
+    s->out_fmt = out_fmt;
+    s->samplerate = samplerate;
+    s->samplenum = samplenum0;
+    s->slab_bytes = slab_bytes;
+    s->slab_out = slab_bytes / ibs * obs;
+    s->slabs.resize((size_t)slabs_per_ctx * (size_t)n_ctx);
+    for (size_t k = 0; k < s->slabs.size(); ++k) {
+        dpx_stream_slab &b = s->slabs[k];
+        b.ctx = ctxs[k % (size_t)n_ctx];                 // consecutive slabs on consecutive GPUs: their copies and kernels overlap
+        hipError_t e = hipSetDevice(b.ctx->device);
+        // A slab's pinned buffers live on the NUMA node of ITS GPU (several GPUs only: one GPU's ring stays where its caller
+        // runs): the pages are taken while the buffer is pinned, under this thread's policy.
+        const int node = n_ctx > 1 ? gpu_numa_node(b.ctx->device) : -1;
+        b.numa_node = node;
+        if (node >= 0) prefer_numa_node(node);
+        // portable: pinned for every device of the process, so that any slab can be handed to any GPU's DMA engines
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_in), slab_bytes, hipHostMallocPortable);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_out), s->slab_out + 16, hipHostMallocPortable);
+        if (node >= 0) {
+            if (e == hipSuccess) { memset(b.h_in, 0, slab_bytes); memset(b.h_out, 0, s->slab_out + 16); }   // first touch under the policy, in case pinning left any page untouched
+            prefer_numa_node(-1);
+        }
+        if (e == hipSuccess) e = hipMalloc(&b.d_in, slab_bytes);
+        if (e == hipSuccess) e = hipMalloc(&b.d_out, s->slab_out + 16);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            dpx_stream_destroy(s);
+            return fail(DPX_ERR_HIP, "stream slab allocation failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (n_ctx > 1) {
+        for (int i = 0; i < n_ctx; ++i) {
+            s->workers.emplace_back(new dpx_stream::Worker);
+            dpx_stream::Worker *w = s->workers.back().get();
+            w->th = std::thread(slab_worker, s, w, s->slabs[(size_t)i].numa_node);
+        }
+    }
+    *out = s;
+    return DPX_OK;
+}
+
+int dpx_stream_create(dpx_ctx *ctx, int in_fmt, int out_fmt, uint32_t samplerate, uint32_t samplenum0,
+                      size_t slab_bytes, int n_slabs, dpx_stream **out)
+{
+    if (!ctx) return fail(DPX_ERR_ARG, "bad argument");
+    return dpx_stream_create_multi(&ctx, 1, in_fmt, out_fmt, samplerate, samplenum0, slab_bytes, n_slabs, out);
+}
+
+void dpx_stream_destroy(dpx_stream *s)
+{
+    if (!s) return;
+    for (auto &w : s->workers) {                     // the enqueue threads finish what they were handed, then leave
+        { std::lock_guard<std::mutex> lk(w->mu); w->stop = true; }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+    }
+    for (dpx_stream_slab &b : s->slabs) {
+        if (b.ctx) (void)hipSetDevice(b.ctx->device);
+        if (b.stream) (void)hipStreamSynchronize(b.stream);
+        if (b.h_in) (void)hipHostFree(b.h_in);
+        if (b.h_out) (void)hipHostFree(b.h_out);
+        if (b.d_in) (void)hipFree(b.d_in);
+        if (b.d_out) (void)hipFree(b.d_out);
+        release(b.dev);
+        if (b.done) (void)hipEventDestroy(b.done);
+        if (b.stream) (void)hipStreamDestroy(b.stream);
+    }
+    delete s;
+}
+
+int dpx_stream_acquire(dpx_stream *s, void **pinned_in, size_t *capacity_bytes)
+{
+    if (!s || !pinned_in) return fail(DPX_ERR_ARG, "bad argument");
+    dpx_stream_slab &b = s->slabs[s->acq];
+    if (b.state != 0) return fail(DPX_ERR_PLAN, "all %zu slabs are in use: call dpx_stream_next/release first", s->slabs.size());
+    b.state = 1;
+    s->acq = (s->acq + 1) % s->slabs.size();
+    *pinned_in = b.h_in;
+    if (capacity_bytes) *capacity_bytes = s->slab_bytes;
+    return DPX_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// the device work of one submitted slab: plan image (unless the slab's resident one is reused), H2D, launch, D2H, event
+int enqueue_slab(dpx_stream *s, dpx_stream_slab &b, double *upload_us, double *enqueue_us)
+{
+    using clk = std::chrono::steady_clock;
+    auto us_since = [](clk::time_point t) { return std::chrono::duration<double, std::micro>(clk::now() - t).count(); };
+    DPX_ENTER(b.ctx);
+    const clk::time_point t1 = clk::now();
+    if (b.out_bytes == 0) {
+        DPX_HIP(hipEventRecord(b.done, b.stream));
+        return DPX_OK;
+    }
+    int rc;
+    if (!b.job_reuse) {
+        rc = materialize(b.ctx, b.plan, b.dev, b.job_fma, b.stream);
+        if (rc != DPX_OK) return rc;
+    }
+    const clk::time_point t2 = clk::now();
+    *upload_us += us_since(t1);
+    DPX_HIP(hipMemcpyAsync(b.d_in, b.h_in, b.job_in_bytes, hipMemcpyHostToDevice, b.stream));
+    rc = run_plan(b.plan, b.dev, b.d_in, s->in_fmt, b.d_out, s->out_fmt, b.job_fma, b.job_geom, b.stream);
+    if (rc != DPX_OK) return rc;
+    DPX_HIP(hipMemcpyAsync(b.h_out, b.d_out, b.out_bytes, hipMemcpyDeviceToHost, b.stream));
+    DPX_HIP(hipEventRecord(b.done, b.stream));
+    *enqueue_us += us_since(t2);
+    return DPX_OK;
+}
+
+void slab_worker(dpx_stream *s, dpx_stream::Worker *w, int numa_node)
+{
+    // run where the GPU's pinned slabs live (sched_setaffinity to the node's CPUs: sysfs cpulist; silent on failure)
+    if (numa_node >= 0) {
+        char path[96];
+        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", numa_node);
+        if (FILE *f = fopen(path, "r")) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            int a = 0, b2 = 0, n = 0;
+            char sep = 0;
+            while (fscanf(f, "%d", &a) == 1) {
+                b2 = a;
+                if (fscanf(f, "%c", &sep) == 1 && sep == '-') { if (fscanf(f, "%d", &b2) != 1) b2 = a; if (fscanf(f, "%c", &sep) != 1) sep = 0; }
+                for (int c = a; c <= b2 && c < CPU_SETSIZE; ++c) { CPU_SET(c, &set); ++n; }
+                if (sep != ',') break;
+            }
+            fclose(f);
+            if (n > 0) (void)sched_setaffinity(0, sizeof set, &set);
+        }
+    }
+    for (;;) {
+        size_t k;
+        {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return w->stop || !w->jobs.empty(); });
+            if (w->jobs.empty()) return;
+            k = w->jobs.front();
+            w->jobs.pop_front();
+        }
+        dpx_stream_slab &b = s->slabs[k];
+        double up = 0, en = 0;
+        b.enq_rc = enqueue_slab(s, b, &up, &en);
+        if (b.enq_rc != DPX_OK) b.enq_err = dpx_last_error();
+        {
+            std::lock_guard<std::mutex> lk(s->enq_mu);
+            s->stats.upload_us += up;
+            s->stats.enqueue_us += en;
+            b.enq.store(2, std::memory_order_release);
+        }
+        s->enq_cv.notify_all();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dpx_stream_submit(dpx_stream *s, size_t in_bytes, const dpx_segment *segs, size_t n_segs)
+{
+    if (!s || (n_segs && !segs)) return fail(DPX_ERR_ARG, "bad argument");
+    dpx_stream_slab &b = s->slabs[s->head];
+    if (b.state != 1) return fail(DPX_ERR_PLAN, "dpx_stream_submit without dpx_stream_acquire");
+    const size_t ibs = bytes_per_sample(s->in_fmt), obs = bytes_per_sample(s->out_fmt);
+    if (in_bytes > s->slab_bytes) return fail(DPX_ERR_CAPACITY, "%zu bytes exceed the slab (%zu)", in_bytes, s->slab_bytes);
+    if (in_bytes % ibs != 0)
+        return fail(DPX_ERR_BLOCK_LEN, "%zu bytes is not a whole number of samples", in_bytes);
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_segs; ++i) total += segs[i].n_samples;
+    if (total != in_bytes / ibs) return fail(DPX_ERR_PLAN, "segments hold %llu samples, the slab %zu",
+                                             (unsigned long long)total, in_bytes / ibs);
+    dpx_ctx *ctx = s->ctx;                 // planning state (period cache, tuning): the first context's
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t0 = clk::now();
+    auto us_since = [](clk::time_point t) { return std::chrono::duration<double, std::micro>(clk::now() - t).count(); };
+    // A slab buffer remembers the plan it ran last and what it was made from: the same segments from the same counter
+    // (const mode whenever the period divides the slab — the headline: every slab after the first round of the ring)
+    // need neither planning nor a new device image, only the copies and the launch.
+    uint32_t sn = s->samplenum;
+    const dpx::LaunchGeom g = geometry(ctx);
+    const SlabKey key = slab_key(ctx, g, segs, n_segs, s->samplerate, sn);
+    bool reuse = total != 0 && b.have_key && b.key == key && b.key_segs.size() == n_segs;
+    for (size_t i = 0; reuse && i < n_segs; ++i)             // field by field: the structs have padding
+        reuse = b.key_segs[i].n_samples == segs[i].n_samples && memcmp(&b.key_segs[i].shift_hz, &segs[i].shift_hz, sizeof(float)) == 0;
+    if (reuse) {
+        sn = b.key_sn_after;
+        ++s->stats.plans_reused;
+    } else {
+        b.have_key = false;
+        b.plan = dpx::PlanResult();
+        // the context remembers every ratio's period: a constant shift is scanned once per run, not once per slab
+        append_segments(b.plan, segs, n_segs, s->samplerate, sn, ctx->variant, ctx->periods);
+        dpx::finalize(b.plan, g.tile(), ctx->choice, ctx->tuning);
+        if (b.plan.error) return fail(DPX_ERR_PLAN, "%s", b.plan.error);
+    }
+    s->stats.plan_us += us_since(t0);
+    b.out_bytes = (size_t)total * obs;
+    b.job_in_bytes = in_bytes;
+    b.job_reuse = reuse;
+    b.job_geom = g;
+    b.job_fma = ctx->fma;
+    if (total && !reuse) {                  // (the key describes the plan; a failed enqueue is reported by dpx_stream_next)
+        b.key = key;
+        b.key_segs.assign(segs, segs + n_segs);
+        b.key_sn_after = sn;
+        b.have_key = true;
+    }
+    if (s->workers.empty()) {
+        double up = 0, en = 0;
+        const int rc = enqueue_slab(s, b, &up, &en);
+        if (rc != DPX_OK) { b.have_key = false; return rc; }
+        s->stats.upload_us += up;
+        s->stats.enqueue_us += en;
+        b.enq.store(0, std::memory_order_relaxed);
+    } else {
+        // the device work goes to the thread of this slab's GPU; dpx_stream_next waits for it, then for the event
+        dpx_stream::Worker &w = *s->workers[s->head % s->workers.size()];
+        b.enq.store(1, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(w.mu);
+            w.jobs.push_back(s->head);
+        }
+        w.cv.notify_one();
+    }
+    ++s->stats.slabs;
+    s->stats.total_us += us_since(t0);
+    s->samplenum = sn;
+    b.state = 2;
+    s->head = (s->head + 1) % s->slabs.size();
+    s->in_flight++;
+    return DPX_OK;
+}
+
+int dpx_stream_pending(const dpx_stream *s, int *n)
+{
+    if (!s || !n) return fail(DPX_ERR_ARG, "bad argument");
+    *n = s->in_flight;
+    return DPX_OK;
+}
+
+int dpx_stream_next(dpx_stream *s, const void **pinned_out, size_t *out_bytes)
+{
+    if (!s || !pinned_out || !out_bytes) return fail(DPX_ERR_ARG, "bad argument");
+    dpx_stream_slab &b = s->slabs[s->tail];
+    if (b.state != 2) return fail(DPX_ERR_PLAN, "nothing in flight");
+    if (b.enq.load(std::memory_order_acquire) != 0) {          // several GPUs: the slab's enqueue thread first
+        std::unique_lock<std::mutex> lk(s->enq_mu);
+        s->enq_cv.wait(lk, [&] { return b.enq.load(std::memory_order_acquire) == 2; });
+        lk.unlock();
+        b.enq.store(0, std::memory_order_relaxed);
+        if (b.enq_rc != DPX_OK) {
+            b.have_key = false;
+            b.state = 3;                                       // the slab is handed out (empty) so that the ring keeps turning
+            s->tail = (s->tail + 1) % s->slabs.size();
+            *pinned_out = b.h_out;
+            *out_bytes = 0;
+            return fail(b.enq_rc, "%s", b.enq_err.c_str());
+        }
+        DPX_HIP(hipSetDevice(b.ctx->device));
+    }
+    DPX_HIP(hipEventSynchronize(b.done));
+    b.state = 3;
+    s->tail = (s->tail + 1) % s->slabs.size();
+    *pinned_out = b.h_out;
+    *out_bytes = b.out_bytes;
+    return DPX_OK;
+}
+
+int dpx_stream_release(dpx_stream *s)
+{
+    if (!s) return fail(DPX_ERR_ARG, "bad argument");
+    dpx_stream_slab &b = s->slabs[s->rel];
+    if (b.state != 3) return fail(DPX_ERR_PLAN, "dpx_stream_release without dpx_stream_next");
+    b.state = 0;
+    s->rel = (s->rel + 1) % s->slabs.size();
+    s->in_flight--;
+    return DPX_OK;
+}
+
+int dpx_stream_get_stats(const dpx_stream *s, dpx_stream_stats *out)
+{
+    if (!s || !out) return fail(DPX_ERR_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(s->enq_mu);          // the enqueue threads add their parts under this lock
+    *out = s->stats;
+    return DPX_OK;
+}
+
+int dpx_stream_samplenum(const dpx_stream *s, uint32_t *samplenum)
+{
+    if (!s || !samplenum) return fail(DPX_ERR_ARG, "bad argument");
+    *samplenum = s->samplenum;
+    return DPX_OK;
+}
+
+}  // extern "C"

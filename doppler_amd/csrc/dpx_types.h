@@ -60,6 +60,7 @@ struct LaunchGeom {
     int vecs;     // 4-sample groups per lane: 1 or 2
     int autosel = 0;   // the caller set neither: 128 x 2 or 256 x 1 (the same 1024-sample tile) is chosen per launch
     int legacy_cast = 0;   // dpx_set_i16_cast(DPX_CAST_LEGACY_X86): i16 output wraps instead of saturating (every kernel: a launch-uniform flag)
+    uint32_t sub_lg = 0;   // tile launches are dealt out in pieces of about 2^sub_lg samples (0: kSubLaunchLg)
     uint32_t tile() const { return (uint32_t)block * kSamplesPerLane * (uint32_t)vecs; }
 };
 
@@ -174,7 +175,20 @@ struct WalkArgs {
     uint32_t span;         // most rows per span the descriptors were cut for
     WalkUni uni;           // launches of one matrix
     uint32_t auto_shape;   // the caller named neither walk_waves nor walk_span: the launch may choose per format pair
+    uint32_t sub_lg;       // the grid is dealt out in pieces of about 2^sub_lg samples (0: kSubLaunchLg; sub_launch_pieces)
+    uint64_t cover;        // samples the launch produces (matrices and leftover ranges)
 };
+
+// Long launches are cut into sub-launches back to back on the stream (dpx_kernels.hip, span_t: 2-3 points at 4-8 GiB):
+// how many pieces a launch over n samples becomes.  sub_lg >= 48 never cuts (measurement).
+constexpr uint32_t kSubLaunchLg = 28;                    // 2^28 samples: 1 GiB of i16 in
+inline uint32_t sub_launch_pieces(uint64_t n, uint32_t sub_lg)
+{
+    const uint32_t lg = sub_lg ? sub_lg : kSubLaunchLg;
+    if (lg >= 48) return 1;
+    const uint64_t per = 1ull << lg, k = (n + per / 2) / per;      // 1.4 pieces' worth stays one launch
+    return k < 1 ? 1u : k > 4096 ? 4096u : (uint32_t)k;
+}
 
 // What ONE launch makes of a plan's span shape for its format pair (the plan does not know the formats): dpx_planner.cpp,
 // span_launch_shape — used by the launch wrapper and by the planner's host simulation alike.
@@ -208,11 +222,15 @@ struct TileArgs {
 constexpr int kResidentSlots = 4;
 constexpr int kResidentThreads = 512;      // one quad per thread for the reference's 2048-sample block
 struct BlockCtl {
-    // ---- written by the host, read by the kernel (one 64-byte line)
+    // ---- written by the host, read by the kernel (one 64-byte line).  The kernel takes the first 16 bytes in ONE load, but
+    // nothing guarantees that a 16-byte read of host memory over PCIe observes one state of the line, so the word proves
+    // itself (ctl_word_valid): the ticket stands at BOTH ends, and the payload dword carries the ticket's low bits — a read
+    // that mixes dwords of two writes of the slot (consecutive tickets of a slot differ by kResidentSlots) fails the test
+    // and counts as "not rung yet"; the next poll sees the settled word.
     uint32_t doorbell;     // ticket of the block to process; the kernel acts when it differs from `done`; kDoorExit: leave
-    uint32_t n_samples;
-    uint32_t n_segs;       // stretches of this block (DevSeg list in the slot's plan area), at most kResidentMaxSegs
-    uint32_t legacy;       // dpx_set_i16_cast
+    uint32_t payload;      // ctl_payload(): n_samples, n_segs, cast mode, the kernel instance the block is meant for, ticket tag
+    uint32_t reserved;
+    uint32_t doorbell2;    // the ticket again
     uint32_t pad0[12];
     // ---- written by the kernel, read by the host (another line)
     uint32_t done;         // ticket of the last block finished
@@ -220,6 +238,17 @@ struct BlockCtl {
     uint32_t blocks;       // blocks processed since launch (statistics)
     uint32_t pad1[13];
 };
+// payload dword: bits 0-13 n_samples (<= 8192), 14-18 n_segs (<= 16), 19 legacy cast, 20 in_fmt, 21 out_fmt, 22 fma
+// (20-22: the kernel instance — a resident kernel of another instance does not serve the ticket, it leaves), 23-31 ticket tag
+constexpr uint32_t ctl_instance(int in_fmt, int out_fmt, bool fma) { return (uint32_t)in_fmt | ((uint32_t)out_fmt << 1) | (fma ? 4u : 0u); }
+constexpr uint32_t ctl_payload(uint32_t ticket, uint32_t n_samples, uint32_t n_segs, uint32_t legacy, uint32_t instance)
+{
+    return (n_samples & 0x3fffu) | ((n_segs & 0x1fu) << 14) | ((legacy & 1u) << 19) | ((instance & 7u) << 20) | ((ticket & 0x1ffu) << 23);
+}
+constexpr bool ctl_word_valid(uint32_t doorbell, uint32_t payload, uint32_t doorbell2)
+{
+    return doorbell == doorbell2 && (payload >> 23) == (doorbell & 0x1ffu);
+}
 static_assert(sizeof(BlockCtl) == 128, "two lines: host-written and kernel-written");
 struct ResidentShared {    // device memory, one per context
     unsigned long long activity;   // wall clock of the last block any workgroup finished

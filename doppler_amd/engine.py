@@ -86,6 +86,13 @@ class Context:
         check(self._lib.dpx_resident_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def resident_info(self):
+        """dict of dpx_resident_counters: launches, blocks, stops, idle_exits, running, tickets_in_flight, slots_parked;
+        launches == stops + idle_exits + running whenever no call is in progress."""
+        st = _lib.ResidentCounters()
+        check(self._lib.dpx_resident_info(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in _lib.ResidentCounters._fields_ if k != "reserved"}
+
     def set_libm_contraction(self, fma=True):
         check(self._lib.dpx_set_libm_contraction(self._h, 1 if fma else 0))
 

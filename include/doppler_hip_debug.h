@@ -7,7 +7,7 @@
  *   dpx_plan_describe / _layout / _simulate          the planner's stretch list, launch layout and a host mirror of the
  *                                                    kernels' index arithmetic (tests/test_host_logic.py, no device needed);
  *   dpx_debug_copy                                   the memory system's own copy rate (calibration of profiles/);
- *   dpx_stream_get_stats / _pending, dpx_plan_n_samples, dpx_set_resident / dpx_resident_stats   introspection, A/B;
+ *   dpx_stream_get_stats / _pending, dpx_plan_n_samples, dpx_set_resident / dpx_resident_stats / _info   introspection, A/B;
  *   dpx_malloc ... dpx_synchronize                   device memory for callers without a HIP binding (ctypes tests, the CLI).
  */
 #ifndef DOPPLER_HIP_DEBUG_H
@@ -35,7 +35,8 @@ typedef struct dpx_options {
                               * that many rows, one window per workgroup, two rows per wavefront per turn */
     uint32_t walk_flags;     /* bit 0: a span launch of ONE matrix reads its descriptors from memory like a many-matrix launch instead
                               * of taking the matrix from its kernel arguments; bits 8..: row-length target in KiSamples */
-    uint32_t reserved;
+    uint32_t sub_lg;         /* span and tile launches over long streams are dealt out as sub-launches of about 2^sub_lg samples, back
+                              * to back on the stream (0 = the default, 28: 1 GiB of i16; >= 48 = one launch whatever the length) */
     uint64_t walk_tilemin;   /* span plans: uncovered gaps at least this long (samples) get a tile-kernel launch */
 } dpx_options;
 /* applies to plans created afterwards; NULL restores the defaults */
@@ -92,6 +93,19 @@ int dpx_plan_n_samples(const dpx_plan *plan, uint64_t *n_samples);
  * fallback), for A/B timing.  dpx_resident_stats: kernel launches and blocks served through doorbells so far. */
 int dpx_set_resident(dpx_ctx *ctx, int on);
 int dpx_resident_stats(const dpx_ctx *ctx, uint64_t *launches, uint64_t *blocks);
+/* The same with how the launches ended.  Every launch of the resident kernel ends in exactly one of two ways — it was asked
+ * to leave (`stops`: any other work of the context, another format pair, dpx_set_resident(0), dpx_ctx_destroy) or it was
+ * found parked (`idle_exits`: 2 ms without a block, or a ticket meant for another instance of the kernel) — so
+ *     launches == stops + idle_exits + running
+ * holds whenever no call is in progress, on an idle box and on a loaded one (tests assert this, not launch counts). */
+typedef struct dpx_resident_counters {
+    uint64_t launches, blocks, stops, idle_exits;
+    uint32_t running;            /* a kernel has been launched and not yet been seen parked */
+    uint32_t tickets_in_flight;  /* dpx_shift_block_async tickets not yet waited for */
+    uint32_t slots_parked;       /* staging slots whose workgroup is not polling */
+    uint32_t reserved;
+} dpx_resident_counters;
+int dpx_resident_info(dpx_ctx *ctx, dpx_resident_counters *out);
 
 int dpx_stream_pending(const dpx_stream *s, int *n_in_flight);
 /* Host time dpx_stream_submit has spent so far, by part (microseconds, summed over `slabs` calls): planning (stretch list +

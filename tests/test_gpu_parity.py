@@ -991,79 +991,6 @@ def test_async_blocks_whose_plan_wants_a_table(ctx, orc):
         assert_same_bytes(np.concatenate(got), np.concatenate(want), outtype, "async blocks with tiny periods %s->%s" % (intype, outtype))
 
 
-def test_resident_block_kernel_lifecycle(orc):
-    """Round 4: dpx_shift_block / dpx_shift_block_async hand their blocks to a RESIDENT kernel (one workgroup per staging slot
-    polling a doorbell in host memory; dpx_types.h BlockCtl) instead of launching one kernel per block.  Checked here, on a
-    context of its own: blocks really go through doorbells (dpx_resident_stats) and one launch serves thousands; the kernel
-    leaves by itself when idle (2 ms) and the next block starts it again; a change of format pair, a bulk plan, a table-bound
-    block and dpx_synchronize in between each make it leave and come back; resident mode off gives the same bytes through a
-    launch per block; and the context can be destroyed while the kernel is resident.  Bytes and counters against the oracle."""
-    import time
-    import doppler_amd
-    from doppler_amd import dsp
-    c2 = doppler_amd.Context(0)
-    try:
-        rate = 1024000
-        x = make_iq("i16", 2048 * 600, 4242, full_scale=True)
-        want, sn_want = orc.const_stream(x, "i16", "i16", 5001, rate)
-
-        def run(pause_every=0, depth=4):
-            sn, out, tickets = 0, [], []
-            for b in range(600):
-                tk, sn = dsp.shift_block_async(x[b * 8192:(b + 1) * 8192], "i16", "i16", sn, 5001.0, rate, ctx=c2)
-                tickets.append(tk)
-                if len(tickets) == depth:
-                    out.append(dsp.wait(tickets.pop(0), "i16", ctx=c2))
-                if pause_every and b % pause_every == pause_every - 1:
-                    time.sleep(0.01)                     # five idle periods: the kernel has left, tickets still outstanding
-            while tickets:
-                out.append(dsp.wait(tickets.pop(0), "i16", ctx=c2))
-            assert sn == sn_want
-            return np.concatenate(out)
-
-        l0, b0 = c2.resident_stats()
-        assert_same_bytes(run(), want, "i16", "resident kernel, 4 in flight")
-        l1, b1 = c2.resident_stats()
-        assert b1 - b0 == 600 and 1 <= l1 - l0 <= 3, (l0, b0, l1, b1)          # one launch (a loaded box may idle it out once)
-        assert_same_bytes(run(pause_every=100), want, "i16", "resident kernel, idle pauses")
-        l2, b2 = c2.resident_stats()
-        assert b2 - b1 == 600 and l2 - l1 >= 5, (l1, l2)                       # it left during the pauses and came back
-        # the synchronous operator takes the same road; other work of the context in between makes the kernel leave first
-        sn = 0
-        got = []
-        xf = make_iq("f32", 1024 * 8, 4243)
-        wf, _ = orc.const_stream(xf, "f32", "i16", 5001, rate)
-        for b in range(40):
-            o, _, sn = dsp.shift_block(x[b * 8192:(b + 1) * 8192], "i16", "i16", sn, 5001.0, rate, ctx=c2)
-            got.append(o)
-            if b == 10:                                  # a bulk plan on the same context
-                gb, fin = run_bulk(c2, x[:8192 * 64], "i16", "i16", [(2048 * 64, 5001.0)], rate)
-                assert_same_bytes(gb, want[:8192 * 64], "i16", "bulk plan between resident blocks")
-            if b == 20:                                  # another format pair: another kernel
-                snf, gf = 0, []
-                for k in range(8):
-                    o2, _, snf = dsp.shift_block(xf[k * 8192:(k + 1) * 8192], "f32", "i16", snf, 5001.0, rate, ctx=c2)
-                    gf.append(o2)
-                assert_same_bytes(np.concatenate(gf), wf, "i16", "f32 -> i16 blocks in between")
-            if b == 30:
-                c2.synchronize()
-                w0, _, _, _ = orc.shift_block(x[:8192], "i16", "i16", 7, 0.0, rate)     # shift 0: a table-bound block
-                o3, _, _ = dsp.shift_block(x[:8192], "i16", "i16", 7, 0.0, rate, ctx=c2)
-                assert_same_bytes(o3, w0, "i16", "table-bound block between resident blocks")
-        assert_same_bytes(np.concatenate(got), want[:8192 * 40], "i16", "synchronous blocks through the resident kernel")
-        l3, b3 = c2.resident_stats()
-        assert b3 - b2 == 48 and l3 - l2 >= 4, (l2, b2, l3, b3)
-        # resident mode off: a launch per block, the same bytes
-        c2.set_resident(False)
-        assert_same_bytes(run(), want, "i16", "a launch per block")
-        assert c2.resident_stats() == (l3, b3)
-        c2.set_resident(True)
-        tk, _ = dsp.shift_block_async(x[:8192], "i16", "i16", 0, 5001.0, rate, ctx=c2)     # leave a ticket and the kernel behind
-        assert tk != 0
-    finally:
-        c2.close()                                       # destroys the context while the kernel is resident
-
-
 def test_async_blocks_equal_the_synchronous_path_on_the_golden_track_replay(ctx, orc):
     """dpx_shift_block_async / dpx_wait (the loop of main.rs:113-118 with block k + 1 read while block k is on the GPU): the
     golden track replay block by block with two, then four blocks in flight — bytes and counters of the synchronous path

@@ -370,3 +370,16 @@ def test_every_wavefront_of_a_workgroup_reaches_its_barrier(tmp_path):
     resident = {k: v for k, v in kern.items() if "resident_block_kernel" in k}     # polls a doorbell: barriers around its shared words, all uniform
     assert len(resident) == 8
     assert all(v == 0 for k, v in kern.items() if k not in span and k not in resident), {k[:60]: v for k, v in kern.items() if v and k not in span and k not in resident}
+
+
+def test_resident_control_word_proves_itself(tmp_path):
+    """The doorbell word of the resident block kernel (csrc/dpx_types.h, BlockCtl: ticket | payload with the ticket's tag |
+    - | ticket) is read by the GPU as one 16-byte PCIe read that nothing guarantees to be atomic: every mix of dwords from
+    two successive writes of a slot must fail ctl_word_valid unless it IS one of the two writes (tests/cpp/test_ctl_word.cpp
+    enumerates a million of them, around the wraps of the tag and of the ticket).  Host only."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "test_ctl_word"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-o", str(exe), os.path.join(root, "tests", "cpp", "test_ctl_word.cpp")])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "0 mixed words accepted" in r.stdout, r.stdout + r.stderr

@@ -1,10 +1,11 @@
-"""The 600 s replay's one-second segments grouped by the rows of their walk matrix, each group timed as a plan of its own
+"""(RATE=N in the environment: samples per second; an option set may carry "variant": 1.)
+The 600 s replay's one-second segments grouped by the rows of their walk matrix, each group timed as a plan of its own
 under several option sets (JSON list of dpx_options dicts in OPTS; default: the planner's own shape against spans of 8 / 16)."""
 import calendar, json, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench, doppler_amd
-RATE = 1024000
+RATE = int(os.environ.get("RATE", "1024000"))     # samples per second of the replay
 segs = bench.track_segments(600, RATE, "i16", calendar.timegm((2015, 1, 22, 19, 48, 0)))
 edges = [(0, 3), (3, 5), (5, 7), (7, 9), (9, 12), (12, 17), (17, 25), (25, 1 << 30)]
 if os.environ.get("EDGES"):     # e.g. EDGES=0,2,3,4,5,6,7,9 : finer classes (upper edge of the last one open)
@@ -26,14 +27,18 @@ built = []
 for key, sg in classes.items():
     if not sg:
         continue
-    rep = (sg * (1 + 60 // len(sg)))[:max(len(sg), 60)]          # at least 60 seconds of stream per class
+    want = max(60, int(61440000 // RATE))                        # at least 60 seconds and 61 M samples of stream per class
+    rep = (sg * (1 + want // len(sg)))[:max(len(sg), want)]
     n = sum(c for c, _ in rep)
     x = torch.randint(-23170, 23171, (2 * n,), dtype=torch.int16, device=dev)
     out = torch.empty(2 * n, dtype=torch.int16, device=dev)
     for sh in shapes:
-        ctx.set_options(**dict(sh))
+        o = dict(sh)
+        ctx.set_tuning(0, 0, int(o.pop("variant", 3)))      # "variant": 1 in an option set = every corrector per sample (tile kernel)
+        ctx.set_options(**o)
         built.append(dict(key=key, nseg=len(sg), n=n, shape=sh, plan=ctx.plan_segments(rep, RATE), x=x, out=out, ms=[]))
 ctx.set_options()
+ctx.set_tuning(0, 0, 3)
 for b in built:
     for _ in range(10):
         b["plan"].run(b["x"].data_ptr(), "i16", b["out"].data_ptr(), "i16", st.cuda_stream)

@@ -40,6 +40,25 @@ print("| %s | `%s`%s | %d | %.1f | %.1f | %.1f | %.0f | %.1f | %.1f | %.1f |" % 
                                                                  k, med, avg, best, n * bps / med / 1e3, f(med), f(avg), f(best)))
 PY
 }
+if [ "${ROWSET:-default}" = generality ]; then
+# round 5: the workloads the replay path was NOT tuned on — the reference README's own sample rates
+# (256 / 300 ksps, /root/reference/README.md:53-62), 2.4 Msps, configs[4]'s real per-rank chunks, and the stream-size sweep
+for rate in 256000 300000 1024000 2400000; do
+  row "track replay 600 s at $rate sps, i16->i16" 8 track600 rate=$rate
+  row "track replay 600 s at $rate sps, f32->i16" 12 track600 rate=$rate pair=f32:i16
+done
+row "per sample: track replay 600 s at 256000 sps, i16->i16" 8 track600 rate=256000 variant=1
+row "configs[4] rank 0 chunk (450 s of 1 h, f32->i16)" 12 config4r0
+row "configs[4] rank 3 chunk (450 s of 1 h, f32->i16)" 12 config4r3
+row "configs[4] rank 3 chunk, span kernel forced (variant 5)" 12 config4r3 variant=5
+for lg in 28 29 30 31; do
+  row "span: 5001 Hz, 2^$lg samples, i16->i16" 8 const5001 n=$((1 << lg))
+done
+for lg in 28 30 31; do
+  row "rows: 5000 Hz, 2^$lg samples, i16->i16" 8 const5000 n=$((1 << lg))
+done
+row "span: 5001 Hz, 2^30 samples, f32->i16" 12 const5001 n=$((1 << 30)) pair=f32:i16
+else
 row "5000 Hz (headline), i16->i16" 8 const5000
 row "5000 Hz, f32->f32" 16 const5000 pair=f32:f32
 row "5000 Hz, i16->f32" 12 const5000 pair=i16:f32
@@ -79,4 +98,5 @@ row "per sample: track replay 600 s, i16->i16" 8 track600 variant=1
 row "span kernel forced (variant 5): track replay 300 s, f32->i16" 12 track300f pair=f32:i16 variant=5
 row "span: 5001 Hz, f32->i16" 12 const5001 pair=f32:i16
 row "span: 5001 Hz, i16->f32" 12 const5001 pair=i16:f32
+fi
 cat $OUTMD
