@@ -14,6 +14,12 @@ namespace {
 thread_local char g_err[512] = "";
 }
 
+DeviceState &device_state(int device)
+{
+    static DeviceState states[64];                 // hipGetDeviceCount of any node there is; index wraps for safety
+    return states[(unsigned)device % 64u];
+}
+
 int fail(int code, const char *fmt, ...)
 {
     va_list ap;
@@ -227,6 +233,7 @@ int dpx_ctx_create(int device, dpx_ctx **out)
     dpx_ctx *ctx = new (std::nothrow) dpx_ctx;
     if (!ctx) return fail(DPX_ERR_ARG, "out of host memory");
     ctx->device = device;
+    ctx->dev = &device_state(device);
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *e = getenv("DPX_RESIDENT")) ctx->resident_on = atoi(e) != 0;
     hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -253,10 +260,12 @@ int dpx_ctx_create(int device, dpx_ctx **out)
 void dpx_ctx_destroy(dpx_ctx *ctx)
 {
     if (!ctx) return;
+    std::lock_guard<std::recursive_mutex> lock(ctx->dev->mu);
     (void)hipSetDevice(ctx->device);
-    // the resident block kernel leaves before its slots are freed; one that does not answer may still be queued behind
-    // other work and poll them later — nothing of the context is freed under a kernel that has not finished
-    if (resident_stop(ctx) != DPX_OK) (void)hipDeviceSynchronize();
+    // the resident block kernel leaves before its slots are freed (any context's: hipFree waits for the device); one that
+    // does not answer may still be queued behind other work and poll them later — nothing of the context is freed under a
+    // kernel that has not finished
+    if (resident_stop_device(ctx) != DPX_OK || resident_stop(ctx) != DPX_OK) (void)hipDeviceSynchronize();
     if (ctx->rstream) { (void)hipStreamSynchronize(ctx->rstream); (void)hipStreamDestroy(ctx->rstream); }
     if (ctx->rshared) (void)hipFree(ctx->rshared);
     if (ctx->stage_in) (void)hipFree(ctx->stage_in);

@@ -23,6 +23,8 @@
 #include "dpx_planner.h"
 #include "dpx_types.h"
 
+struct dpx_ctx;
+
 namespace dpx_api {
 
 // sets the thread-local message dpx_last_error() returns; returns `code`
@@ -62,6 +64,19 @@ constexpr size_t kSmallPlanBytes = 16 << 10;
 constexpr size_t kSmallInOff = 0, kSmallOutOff = kSmallCallBytes, kSmallPlanOff = 2 * kSmallCallBytes;
 constexpr size_t kSmallCtlOff = 2 * kSmallCallBytes + kSmallPlanBytes;      // dpx::BlockCtl of an asynchronous slot
 constexpr size_t kSlotBytes = kSmallCtlOff + 256;
+
+// Per device, process-wide: ONE lock for every entry point that touches a context of that device, and the context whose
+// resident block kernel is running there, if any.  A resident kernel holds the hardware queue its stream was mapped to, and
+// HIP maps streams to a handful of hardware queues as it pleases: two contexts of one process whose resident kernels land
+// on the same queue take turns at the pace of the 2 ms idle clock (measured: 400 + 400 interleaved blocks in 1.6 s instead of
+// 14 ms), and ANY launch of another context can queue behind a resident kernel that is not its own.  So there is at most one
+// resident kernel per device and process, and every launch of the library on that device asks it to leave first, whichever
+// context started it (contexts that alternate block by block hand it over at ~25 us per block: bounded, and never wrong).
+struct DeviceState {
+    std::recursive_mutex mu;
+    std::atomic<dpx_ctx *> resident_owner{nullptr};
+};
+DeviceState &device_state(int device);
 
 }  // namespace dpx_api
 
@@ -109,9 +124,10 @@ struct dpx_ctx {
     uint64_t resident_launches = 0, resident_blocks = 0;
     uint64_t resident_stops = 0, resident_idle_exits = 0;   // how the launches ended: asked to leave / found parked (idle clock)
     // A context is one caller's at a time (include/doppler_hip.h) — but a context lent to a multi-GPU stream is also used
-    // by that stream's enqueue thread.  Every entry point that touches the stream / staging / resident state holds this
-    // (recursive: dpx_shift_block -> dpx_shift_block_async -> the launch path), so the two never interleave inside one.
-    std::recursive_mutex mu;
+    // by that stream's enqueue thread, and the resident kernel is a matter of the whole device (DeviceState).  Every entry
+    // point that touches the stream / staging / resident state holds the device's lock (recursive: dpx_shift_block ->
+    // dpx_shift_block_async -> the launch path), so two callers never interleave inside one.
+    dpx_api::DeviceState *dev = nullptr;
 };
 static_assert(dpx_ctx::kAsyncSlots == dpx::kResidentSlots, "one resident workgroup per staging slot");
 
@@ -142,7 +158,8 @@ void release(DevPlan &dev);
 
 // ---- dpx_resident.cpp
 int alloc_slot(dpx_ctx::AsyncSlot &a);
-int resident_stop(dpx_ctx *ctx);            // the resident kernel has served what was rung and has left when this returns DPX_OK
+int resident_stop(dpx_ctx *ctx);            // this context's resident kernel has served what was rung and has left when this returns DPX_OK
+int resident_stop_device(dpx_ctx *ctx);     // ... whichever context of ctx's device owns the running kernel
 bool slot_usable(dpx_ctx *ctx, dpx_ctx::AsyncSlot &a);
 
 // ---- dpx_operators.cpp
@@ -152,13 +169,13 @@ int run_host(dpx_ctx *ctx, const void *in, size_t n, int in_fmt, void *out, int 
 }  // namespace dpx_api
 
 // Every entry point that launches or synchronises on a context's behalf passes through here first: the context's lock
-// for the rest of the function, its device current, and a resident block kernel (which holds its hardware queue) gone.
-#define DPX_ENTER(ctx)                                                       \
-    std::lock_guard<std::recursive_mutex> dpx_ctx_lock_((ctx)->mu);          \
-    do {                                                                     \
-        DPX_HIP(hipSetDevice((ctx)->device));                                \
-        if ((ctx)->resident_running.load(std::memory_order_acquire)) {       \
-            const int rc_enter_ = dpx_api::resident_stop(ctx);               \
-            if (rc_enter_ != DPX_OK) return rc_enter_;                       \
-        }                                                                    \
+// for the rest of the function, its device current, and any resident block kernel on that device (which holds a hardware queue) gone.
+#define DPX_ENTER(ctx)                                                             \
+    std::lock_guard<std::recursive_mutex> dpx_ctx_lock_((ctx)->dev->mu);           \
+    do {                                                                           \
+        DPX_HIP(hipSetDevice((ctx)->device));                                      \
+        if ((ctx)->dev->resident_owner.load(std::memory_order_acquire)) {          \
+            const int rc_enter_ = dpx_api::resident_stop_device(ctx);              \
+            if (rc_enter_ != DPX_OK) return rc_enter_;                             \
+        }                                                                          \
     } while (0)

@@ -110,8 +110,8 @@ int dpx_plan_segments(dpx_ctx *ctx, const dpx_segment *segs, size_t n_segs, uint
     hipError_t e = hipSetDevice(ctx->device);
     int rc = e == hipSuccess ? DPX_OK : fail(DPX_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
     if (rc == DPX_OK) {
-        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
-        rc = resident_stop(ctx);
+        std::lock_guard<std::recursive_mutex> lock(ctx->dev->mu);
+        rc = resident_stop_device(ctx);
     }
     if (rc == DPX_OK && p->host.error) rc = fail(DPX_ERR_PLAN, "%s", p->host.error);
     if (rc == DPX_OK && p->host.n_samples) {
@@ -169,9 +169,9 @@ int dpx_run_device(dpx_plan *plan, const void *d_in, int in_fmt, void *d_out, in
     if (plan->host.n_samples == 0) return DPX_OK;
     if (!d_in || !d_out) return fail(DPX_ERR_ARG, "null device pointer");
     if (((uintptr_t)d_in | (uintptr_t)d_out) & 15u) return fail(DPX_ERR_ARG, "device pointers must be 16-byte aligned");
-    if (plan->ctx->resident_running.load(std::memory_order_acquire)) {   // (one load otherwise) a resident block kernel would hold up this launch's queue
-        std::lock_guard<std::recursive_mutex> lock(plan->ctx->mu);
-        const int rc = resident_stop(plan->ctx);
+    if (plan->ctx->dev->resident_owner.load(std::memory_order_acquire)) {   // (one load otherwise) a resident block kernel could hold up this launch's queue
+        std::lock_guard<std::recursive_mutex> lock(plan->ctx->dev->mu);
+        const int rc = resident_stop_device(plan->ctx);
         if (rc != DPX_OK) return rc;
     }
     return run_plan(plan->host, plan->dev, d_in, in_fmt, d_out, out_fmt, plan->fma, plan->geom, hip_stream);

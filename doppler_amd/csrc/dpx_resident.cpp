@@ -79,13 +79,22 @@ int wait_parked(dpx_ctx *ctx, bool asked)
     }
     DPX_HIP(hipStreamSynchronize(ctx->rstream));
     ctx->resident_running.store(false, std::memory_order_release);
+    dpx_ctx *me = ctx;
+    ctx->dev->resident_owner.compare_exchange_strong(me, nullptr);
     if (asked) ++ctx->resident_stops; else ++ctx->resident_idle_exits;
     return DPX_OK;
 }
 
-// start the instance (in_fmt, out_fmt, fma); no kernel may be running
+// start the instance (in_fmt, out_fmt, fma); no kernel of this context may be running — one of ANOTHER context of the
+// device is asked to leave first (dpx_internal.h, DeviceState: one resident kernel per device and process)
 int launch(dpx_ctx *ctx, int in_fmt, int out_fmt, bool fma)
 {
+    if (dpx_ctx *other = ctx->dev->resident_owner.load(std::memory_order_acquire)) {
+        if (other != ctx) {
+            const int rc = resident_stop(other);
+            if (rc != DPX_OK) return rc;
+        }
+    }
     for (auto &a : ctx->async_slots) {
         const int rc = alloc_slot(a);
         if (rc != DPX_OK) return rc;
@@ -113,6 +122,7 @@ int launch(dpx_ctx *ctx, int in_fmt, int out_fmt, bool fma)
         return fail(rc, "resident block kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     }
     ctx->resident_running.store(true, std::memory_order_release);
+    ctx->dev->resident_owner.store(ctx, std::memory_order_release);
     ctx->resident_in = in_fmt;
     ctx->resident_out = out_fmt;
     ctx->resident_fma = fma;
@@ -203,6 +213,8 @@ bool slot_usable(dpx_ctx *ctx, dpx_ctx::AsyncSlot &a)
     if (!all_parked(ctx)) return false;
     for (auto &s : ctx->async_slots) s.poisoned = false;
     ctx->resident_running.store(false, std::memory_order_release);
+    dpx_ctx *me = ctx;
+    ctx->dev->resident_owner.compare_exchange_strong(me, nullptr);
     return true;
 }
 
@@ -218,6 +230,12 @@ int resident_stop(dpx_ctx *ctx)
     for (auto &a : ctx->async_slots)
         if (a.host) ring(slot_ctl(a), dpx::kDoorExit, 0, 0, 0, 0);
     return wait_parked(ctx, true);
+}
+
+int resident_stop_device(dpx_ctx *ctx)
+{
+    dpx_ctx *owner = ctx->dev->resident_owner.load(std::memory_order_acquire);
+    return owner ? resident_stop(owner) : DPX_OK;
 }
 
 }  // namespace dpx_api
@@ -237,7 +255,7 @@ int dpx_shift_block_async(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_
                     in_fmt == DPX_FMT_I16 ? "i16" : "f32");
     const size_t n = in_bytes / bytes_per_sample(in_fmt);
     if (n * 8 > kSmallCallBytes) return fail(DPX_ERR_CAPACITY, "an asynchronous block holds at most %zu samples", kSmallCallBytes / 8);
-    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->dev->mu);
     DPX_HIP(hipSetDevice(ctx->device));
     const uint32_t seq = ctx->async_next_seq;
     dpx_ctx::AsyncSlot &a = ctx->async_slots[seq % dpx_ctx::kAsyncSlots];
@@ -261,7 +279,7 @@ int dpx_shift_block_async(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_
         return DPX_OK;
     };
     if (n == 0) {
-        rc = resident_stop(ctx);
+        rc = resident_stop_device(ctx);
         if (rc != DPX_OK) return rc;
         DPX_HIP(hipEventRecord(a.done, ctx->stream));
         return issue(sn);
@@ -297,7 +315,7 @@ int dpx_shift_block_async(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_
         if (ctx->resident_on) return rc;              // (a kernel that does not answer turns the mode off: the launch path below)
     }
     // ---- one launch per block (round 3's path): periods the resident kernel's slot cannot hold, or resident mode off
-    rc = resident_stop(ctx);
+    rc = resident_stop_device(ctx);
     if (rc != DPX_OK) return rc;
     if (!slot_usable(ctx, a)) return fail(DPX_ERR_HIP, "a resident block kernel that stopped answering still holds this context's staging slots");
     {
@@ -330,7 +348,7 @@ int dpx_shift_block_async(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_
 int dpx_wait(dpx_ctx *ctx, dpx_ticket ticket, void *out, size_t out_cap, size_t *n_samples_out)
 {
     if (!ctx || ticket == 0) return fail(DPX_ERR_ARG, "bad argument");
-    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->dev->mu);
     dpx_ctx::AsyncSlot &a = ctx->async_slots[ticket % dpx_ctx::kAsyncSlots];
     if (a.seq != ticket) return fail(DPX_ERR_ARG, "ticket %u is not in flight", ticket);
     if (a.out_bytes > out_cap || (!out && a.out_bytes))
@@ -378,7 +396,7 @@ int dpx_wait(dpx_ctx *ctx, dpx_ticket ticket, void *out, size_t out_cap, size_t 
 int dpx_set_resident(dpx_ctx *ctx, int on)
 {
     if (!ctx) return fail(DPX_ERR_ARG, "ctx is null");
-    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->dev->mu);
     if (!on) {
         const int rc = resident_stop(ctx);
         if (rc != DPX_OK) return rc;
@@ -398,7 +416,7 @@ int dpx_resident_stats(const dpx_ctx *ctx, uint64_t *launches, uint64_t *blocks)
 int dpx_resident_info(dpx_ctx *ctx, dpx_resident_counters *out)
 {
     if (!ctx || !out) return fail(DPX_ERR_ARG, "bad argument");
-    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->dev->mu);
     memset(out, 0, sizeof *out);
     out->launches = ctx->resident_launches;
     out->blocks = ctx->resident_blocks;

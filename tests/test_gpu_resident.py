@@ -142,10 +142,11 @@ def test_tickets_of_two_kernel_instances_in_flight_together(orc):
 
 
 def test_two_contexts_on_one_device_interleave_async_blocks(orc):
-    """Two contexts on device 0, each with a resident kernel of its own (two polling kernels, two hardware queues), their
-    asynchronous blocks interleaved by one host thread: different shifts, different format pairs, four tickets in flight
-    each.  Neither waits for the other's kernel to leave (the whole test would take minutes if every block paid an idle
-    period), and both streams are the oracle's."""
+    """Two contexts on device 0, their asynchronous blocks interleaved by one host thread: different shifts, different format
+    pairs, four tickets in flight each.  There is ONE resident kernel per device and process (csrc/dpx_internal.h,
+    DeviceState): HIP may map the two contexts' streams to one hardware queue, where two resident kernels take turns at the
+    pace of the 2 ms idle clock (measured before the rule: 400 + 400 blocks in 1.6 s) — so the contexts hand the kernel
+    over instead, block by block here, which is the worst case.  Both streams are the oracle's; the hand-over is bounded."""
     import doppler_amd
     from doppler_amd import dsp
     ca, cb = doppler_amd.Context(0), doppler_amd.Context(0)
@@ -166,6 +167,8 @@ def test_two_contexts_on_one_device_interleave_async_blocks(orc):
             if len(ta) == 4:
                 ga.append(dsp.wait(ta.pop(0), "i16", ctx=ca))
                 gb.append(dsp.wait(tb.pop(0), "i16", ctx=cb))
+            ia, ib = ca.resident_info(), cb.resident_info()
+            assert ia["running"] + ib["running"] <= 1, (ia, ib)          # never two resident kernels on the device
         while ta:
             ga.append(dsp.wait(ta.pop(0), "i16", ctx=ca))
             gb.append(dsp.wait(tb.pop(0), "i16", ctx=cb))
@@ -175,10 +178,17 @@ def test_two_contexts_on_one_device_interleave_async_blocks(orc):
         assert_same_bytes(np.concatenate(gb), wb, "i16", "context B")
         ia, ib = consistent(ca.resident_info()), consistent(cb.resident_info())
         assert ia["blocks"] == nb and ib["blocks"] == nb
-        # both kernels were resident side by side: had they taken turns on one queue, each of the 800 blocks would have
-        # waited out the other kernel's 2 ms idle clock (> 1.6 s)
-        print("two contexts: %d + %d blocks in %.3f s; launches %d / %d" % (nb, nb, dt, ia["launches"], ib["launches"]))
-        assert dt < 1.6 or (ia["launches"] + ib["launches"]) < nb // 4, (dt, ia, ib)
+        print("two contexts: %d + %d blocks in %.3f s (%.1f us per block); launches %d / %d, idle exits %d / %d" % (
+            nb, nb, dt, dt / (2 * nb) * 1e6, ia["launches"], ib["launches"], ia["idle_exits"], ib["idle_exits"]))
+        # handed over, not idled out: had every block waited for the other kernel's idle clock, 800 x 2 ms = 1.6 s
+        assert ia["idle_exits"] + ib["idle_exits"] < nb // 4 or dt < 0.8, (dt, ia, ib)
+        # a stretch of blocks on ONE context afterwards keeps its kernel: no hand-over without a second user
+        l0 = ca.resident_info()["launches"]
+        sn = 0
+        for b in range(50):
+            o, _, sn = dsp.shift_block(xa[b * 8192:(b + 1) * 8192], "i16", "i16", sn, 5001.0, rate, ctx=ca)
+            assert_same_bytes(o, wa[b * 8192:(b + 1) * 8192], "i16", "context A alone, block %d" % b)
+        assert ca.resident_info()["launches"] - l0 <= 50 // 2             # (a loaded box may idle it out now and then)
     finally:
         ca.close()
         cb.close()
