@@ -104,23 +104,39 @@ def track_segments(seconds, rate, in_fmt, start_unix, frequency=437505000, offse
     return [(int((e - s0) * spb), float(hz[s0])) for s0, e in zip(starts, ends)]
 
 
-def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True):
-    """Secondary workload (BASELINE.json configs[2] at N=1, configs[4] at N>1); never the default `value`."""
+REPLAYS = {
+    # name -> (seconds, samplerate, in, out, start (UTC), offset_hz, what)
+    "track": (600, 1024000, "i16", "i16", (2015, 1, 22, 19, 48, 0), 5000,
+              "doppler track -s 1024000 -i i16 (synthetic ESTCUBE-1-like TLE, --time replay of a 10 min overpass, --offset 5000): BASELINE.json configs[2]"),
+    "track_256k": (600, 256000, "i16", "i16", (2015, 1, 22, 19, 48, 0), -2500,
+                   "doppler track -s 256000 -i i16 --offset -2500, --time replay of the same 10 min overpass: the reference README's own "
+                   "recording recipe (README.md:60)"),
+    "config4_chunk": (3600, 1024000, "f32", "i16", (2015, 1, 22, 19, 23, 0), 5000,
+                      "doppler track -s 1024000 -i f32 -o i16, 1 h replay: rank 3 of 8's time chunk (460.8 M samples, counter seeded from "
+                      "the closed form): one GPU's share of BASELINE.json configs[4]"),
+}
+SETTLE_S = 0.15     # untimed launches before the settled measurement of a secondary workload (clocks: profiles/r02_walk.md)
+
+
+def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True, which="track"):
+    """Secondary workloads (never the default `value`): `track` = BASELINE.json configs[2] at N=1 and configs[4] sharded at
+    N>1; `track_256k` and `config4_chunk` (N=1 only) are the replays the kernels were NOT tuned on.
+    Every line carries TWO fractions of the same K launches' worth of work: `frac_cold` — K launches right after the
+    W warm-up launches, the headline's own rule — and `frac` — K launches after a further SETTLE_S of untimed launches
+    (`untimed_settling_ms`), the steady state a long stream sees."""
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     import calendar
     from doppler_amd import shard
-    rate = 1024000
-    if world == 1:
-        seconds, it, ot, start = 600, "i16", "i16", calendar.timegm((2015, 1, 22, 19, 48, 0))
-        name = "doppler track -s 1024000 -i i16 (synthetic ESTCUBE-1-like TLE, --time replay of a 10 min overpass, --offset 5000)"
-    else:
-        seconds, it, ot, start = 3600, "f32", "i16", calendar.timegm((2015, 1, 22, 19, 23, 0))
+    seconds, rate, it, ot, start, offset, name = REPLAYS[which]
+    if which == "track" and world > 1:
+        seconds, rate, it, ot, start, offset, name = REPLAYS["config4_chunk"]
         name = "doppler track -s 1024000 -i f32 -o i16, 1 h replay sharded in time chunks over %d GPUs, --offset 5000" % world
     bi, bo = (4 if it == "i16" else 8), (4 if ot == "i16" else 8)
-    segs = track_segments(seconds, rate, it, start)
-    total = seconds * rate
-    lo, hi = shard.chunk_bounds(total, world, rank, bytes_per_sample=bi)
+    segs = track_segments(seconds, rate, it, calendar.timegm(start), offset=offset)
+    total = sum(c for c, _ in segs)
+    shards, shard_rank = (8, 3) if which == "config4_chunk" else (world, rank)
+    lo, hi = shard.chunk_bounds(total, shards, shard_rank, bytes_per_sample=bi)
     before, inside = shard.segments_for_chunk(segs, lo, hi)
     import doppler_amd
     n = hi - lo
@@ -144,57 +160,64 @@ def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def timed():
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(steps):
+            plan.run(x.data_ptr(), it, out.data_ptr(), ot, stream.cuda_stream)
+        ev1.record(stream)
+        barrier()
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
+
     for _ in range(warmup):
         plan.run(x.data_ptr(), it, out.data_ptr(), ot, stream.cuda_stream)
-    settle_ms = 0.0
-    if not emit:
-        # Riding along after the headline (`extra`): the K launches of this kernel last ~20 ms, and the chip needs 50-100 ms
-        # under load to settle its clocks (profiles/r02_walk.md) — launch untimed for 150 ms first, so that the figure is the
-        # steady-state one that `bench.py --workload track` (300 steps by default) reports.
-        t_s = time.perf_counter()
-        while time.perf_counter() - t_s < 0.15:
-            for _ in range(10):
-                plan.run(x.data_ptr(), it, out.data_ptr(), ot, stream.cuda_stream)
-            torch.cuda.synchronize(dev)
-        settle_ms = (time.perf_counter() - t_s) * 1e3
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(steps):
-        plan.run(x.data_ptr(), it, out.data_ptr(), ot, stream.cuda_stream)
-    ev1.record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    _, kms_cold = timed()                      # the headline's rule: W warm-up launches, then K timed ones
+    t_s = time.perf_counter()
+    while time.perf_counter() - t_s < SETTLE_S:
+        for _ in range(10):
+            plan.run(x.data_ptr(), it, out.data_ptr(), ot, stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+    settle_ms = (time.perf_counter() - t_s) * 1e3
+    elapsed, kms = timed()
     if DIST_ON:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     line = None
     if rank == 0:
-        kms = ev0.elapsed_time(ev1) / steps
-        ach = n * (bi + bo) / (kms * 1e-3) / 1e9
-        prof = profiled("track") if world == 1 else None
-        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": prof["hbm_bytes_per_launch"] if prof else None,
-                "kernel": ("dpx::span_kernel" if layout["walk_launches"] and not ((it, ot) == ("f32", "i16") and layout.get("f32_i16_by_tiles"))
-                           else "dpx::tile_kernel"), "layout": layout,
-                "avg_launch_ms": round(kms, 4), "algorithmic_bytes_per_launch": n * (bi + bo)}
+        alg = n * (bi + bo)
+        frac = lambda ms: round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        prof = profiled(which) if world == 1 else None
+        by_tiles = (it, ot) == ("f32", "i16") and layout.get("f32_i16_by_tiles")
+        roof = {"bound": "hbm", "achieved": round(alg / (kms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": frac(kms), "frac_cold": frac(kms_cold),
+                "frac_is": "K launches after %d ms of untimed launches (settled clocks); frac_cold: K launches right after the W warm-up "
+                           "launches, the headline's rule" % round(settle_ms),
+                "traffic": prof["hbm_bytes_per_launch"] if prof and "hbm_bytes_per_launch" in prof else None,
+                "kernel": "dpx::span_kernel" if layout["walk_launches"] and not by_tiles else "dpx::tile_kernel", "layout": layout,
+                "avg_launch_ms": round(kms, 4), "avg_launch_ms_cold": round(kms_cold, 4), "algorithmic_bytes_per_launch": alg}
         if prof and prof.get("avg_launch_us_kernel_trace"):
-            roof["frac_rocprof"] = round(n * (bi + bo) / (prof["avg_launch_us_kernel_trace"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+            # from the committed rocprofv3 kernel trace of this workload (same kernel sources): ALL its launches, and the ones
+            # that start more than 160 ms after the first
+            roof["frac_rocprof"] = round(alg / (prof["avg_launch_us_kernel_trace"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+            if prof.get("settled_avg_us"):
+                roof["frac_rocprof_settled"] = round(alg / (prof["settled_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
         line = {
-            "metric": "Msamples/s IQ throughput + % HBM roofline (track replay, secondary workload)",
-            "value": round(total * steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": world, "steps": steps,
-            "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True,
+            "metric": "Msamples/s IQ throughput + %% HBM roofline (%s replay, secondary workload)" % which,
+            "value": round((total if which != "config4_chunk" else n) * steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "untimed_settling_ms": round(settle_ms, 1), "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": name, "samples_total": total, "samples_per_gpu": n, "segments_total": len(segs),
                        "segments_this_rank": len(inside), "plan_ms": round(plan_ms, 2), "one_shot_ms": round(one_shot_ms, 2),
-                       "in": it, "out": ot, "untimed_settling_ms": round(settle_ms, 1)},
+                       "in": it, "out": ot, "samplerate": rate, "offset_hz": offset},
             "roofline": roof,
         }
         if emit:
             print(json.dumps(line), flush=True)
     plan.close()
+    del x, out
     return line
 
 
@@ -232,7 +255,7 @@ def per_rank_report(rank, dev_index, avg_kernel_ms, elapsed_s):
 
 
 GATHER_TIMEOUT_S = 240
-PMC_PROFILE = "r04_pmc_traffic.json"     # tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes + a kernel-trace pass
+PMC_PROFILE = "r05_pmc_traffic.json"     # tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes + a kernel-trace pass
 KERNEL_SOURCES = ["doppler_amd/csrc/dpx_kernels.hip", "doppler_amd/csrc/dpx_sincos.h", "doppler_amd/csrc/dpx_types.h"]
 
 
@@ -275,7 +298,7 @@ def build_result(args, world, n, elapsed, avg_kernel_ms, gather, plan_ms=None, o
                           "none: no PMC profile of these kernel sources is committed (sha %s)" % kernel_source_sha(),
     }
     if prof and prof.get("avg_launch_us_kernel_trace"):
-        us = prof["avg_launch_us_kernel_trace"]
+        us = prof["avg_launch_us_kernel_trace"]          # ALL launches of the committed kernel trace, warm-up included
         roof["frac_rocprof"] = round(n * BYTES_PER_SAMPLE / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
         roof["avg_launch_us_rocprof"] = us
     result = {
@@ -324,9 +347,9 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (track) workload appended under `extra`")
-    ap.add_argument("--workload", default="const", choices=["const", "track"],
-                    help="const = the headline (default); track = secondary track-replay workload")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (replay) workloads appended under `extra`")
+    ap.add_argument("--workload", default="const", choices=["const"] + sorted(REPLAYS),
+                    help="const = the headline (default); track / track_256k / config4_chunk = secondary replay workloads")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -361,8 +384,10 @@ def main():
     ctx = doppler_amd.Context(dev_index)
     global T_CTX
     T_CTX = time.perf_counter()
-    if args.workload == "track":
-        run_track(args, world, rank, dev, ctx)
+    if args.workload != "const":
+        if args.workload != "track" and world > 1:
+            raise SystemExit("--workload %s is a one-GPU workload" % args.workload)
+        run_track(args, world, rank, dev, ctx, which=args.workload)
         if DIST_ON:
             dist.barrier()
             dist.destroy_process_group()
@@ -532,13 +557,17 @@ def main():
             torch.cuda.empty_cache()
             t_leg = time.perf_counter()
             if not args.no_extra:
-                # secondary workload (BASELINE.json configs[2]), after the timed region: rides along in the driver's record
-                try:
-                    result["extra"] = {"track": run_track(args, 1, 0, dev, ctx, steps=min(args.steps, 20),
-                                                          warmup=min(args.warmup, 3), emit=False)}
-                except Exception as e:
-                    result["extra"] = {"track": {"error": str(e)[:300]}}
-                LEGS["extra_track"] = round(time.perf_counter() - t_leg, 3)
+                # secondary workloads, after the timed region: they ride along in the driver's record.  BASELINE.json
+                # configs[2], the reference README's 256 ksps recording recipe, one GPU's chunk of configs[4].
+                result["extra"] = {}
+                for which in ("track", "track_256k", "config4_chunk"):
+                    try:
+                        result["extra"][which] = run_track(args, 1, 0, dev, ctx, steps=min(args.steps, 20),
+                                                           warmup=min(args.warmup, 3), emit=False, which=which)
+                    except Exception as e:
+                        result["extra"][which] = {"error": str(e)[:300]}
+                    torch.cuda.empty_cache()
+                LEGS["extra_replays"] = round(time.perf_counter() - t_leg, 3)
         LEGS["import_and_context"] = round(T_CTX - T_START, 3)
         result["legs_s"] = dict(LEGS)
         print(json.dumps(result), flush=True)

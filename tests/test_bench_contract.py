@@ -33,3 +33,46 @@ def test_result_line_schema():
     assert rf["algorithmic_bytes_per_launch"] == n * 8 and line["gather"] == {"ms": 12.5}
     # no process group in this test: the line says so (under the driver: "nccl" and the world RCCL reported)
     assert line["backend"] is None and line["world_size_seen"] == 1
+
+
+def test_check_scale_names_what_is_off(tmp_path):
+    """tools/check_scale.py against synthetic driver records: a curve as DESIGN.md section 6 predicts passes; a slow rank, two
+    ranks on one GPU, a gloo backend, a wrong world size, a serialised gather and a skipped record are each named."""
+    import copy
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_scale
+    args = argparse.Namespace(steps=300, warmup=10)
+    n = bench.N_SAMPLES
+
+    def line(world, kernel_ms=0.320, slow_rank=None, gather_ms=8.0):
+        per_rank = [dict(rank=r, device=r, pci_bus_id="0000:%02x:00.0" % (5 + r), avg_kernel_ms=kernel_ms * (1.12 if r == slow_rank else 1.0),
+                         timed_region_s=0.0962) for r in range(world)]
+        worst = max(p["avg_kernel_ms"] for p in per_rank)
+        ln = bench.build_result(args, world, n, elapsed=300 * worst * 1e-3, avg_kernel_ms=kernel_ms,
+                                gather={"ms": gather_ms, "bytes_per_rank": 4 * n, "per_peer": [{"peer": p, "ms": 7.1, "GB_per_s": 151.0} for p in range(1, world)],
+                                        "per_gpu_d2h": {"ms": 20.1}} if world > 1 else None, per_rank=per_rank)
+        ln["backend"], ln["world_size_seen"] = ("nccl", world) if world > 1 else (None, 1)
+        return json.loads(json.dumps(ln))
+
+    good = {"runs": [{"parsed": line(w)} for w in (1, 2, 4, 8)]}
+    p = tmp_path / "SCALE_ok.json"
+    p.write_text(json.dumps(good))
+    assert check_scale.main([str(p)]) == 0
+    assert check_scale.check_line(line(8)) == []
+    f = check_scale.check_line(line(8, slow_rank=5))
+    assert any("rank 5" in x and "0000:0a:00.0" in x for x in f) and any("value" in x for x in f), f
+    bad = line(4)
+    bad["per_rank"][2]["pci_bus_id"] = bad["per_rank"][1]["pci_bus_id"]
+    bad["backend"], bad["world_size_seen"] = "gloo", 3
+    f = " | ".join(check_scale.check_line(bad))
+    assert "distinct GPUs" in f and "backend 'gloo'" in f and "world_size_seen 3" in f, f
+    f = " | ".join(check_scale.check_line(line(8, gather_ms=52.0)))
+    assert "RCCL gather 52.0 ms" in f, f
+    slow_peer = copy.deepcopy(line(4))
+    slow_peer["gather"]["per_peer"][1]["ms"] = 30.0
+    assert any("peer 2" in x for x in check_scale.check_line(slow_peer))
+    q = tmp_path / "SCALE_skipped.json"
+    q.write_text(json.dumps({"skipped": True, "reason": "no 8-GPU node"}))
+    assert check_scale.main([str(q)]) == 2
+    assert check_scale.main([str(q), str(p)]) == 0

@@ -653,19 +653,23 @@ def test_full_size_config0_f32_stream(ctx, orc):
     assert_same_bytes(got, want, "f32", "configs[0]")
 
 
-def test_full_size_track_replay(ctx, orc):
+@pytest.mark.parametrize("which", ["track", "track_256k"])
+def test_full_size_track_replay(ctx, orc, which):
     """BASELINE.json configs[2] at full size: the 10-minute replay of bench.py --workload track (614 400 000 samples of
-    i16 IQ, 600 one-second shifts from the host SGP4 + the reference's schedule), one walk-kernel launch, compared byte
-    for byte with the oracle: every segment evaluated by the oracle's convert / shift_frequency / pack from the sequential counter the
-    oracle itself carries across the segments (segments run on all host cores)."""
+    i16 IQ, 600 one-second shifts from the host SGP4 + the reference's schedule, main.rs:156-184), and the same overpass at the
+    reference README's own recording rate (bench.py --workload track_256k: 256 ksps, --offset -2500, README.md:60 — a quarter
+    of the samples per second, so three times the share of seconds with fewer than five periods).  One span-kernel launch each,
+    compared byte for byte with the oracle: every segment evaluated by the oracle's convert / shift_frequency / pack from the
+    sequential counter the oracle itself carries across the segments (segments run on all host cores)."""
     import calendar
     import sys
     from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     import doppler_amd
-    rate = 1024000
-    segs = bench.track_segments(600, rate, "i16", calendar.timegm((2015, 1, 22, 19, 48, 0)))
+    seconds, rate, it, ot, start, offset, _ = bench.REPLAYS[which]
+    assert (it, ot) == ("i16", "i16")
+    segs = bench.track_segments(seconds, rate, "i16", calendar.timegm(start), offset=offset)
     n = sum(c for c, _ in segs)
     assert n == 600 * rate and doppler_amd.plan_layout(segs, rate)["walk_launches"] == 1
     rng = np.random.default_rng(3)

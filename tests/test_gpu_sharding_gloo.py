@@ -127,6 +127,13 @@ def test_bench_multi_rank_code_path_on_a_shared_gpu(world):
     assert all(r_["avg_kernel_ms"] > 0 and "pci_bus_id" in r_ for r_ in line["per_rank"]), line["per_rank"]
     assert [p["peer"] for p in line["gather"]["per_peer"]] == list(range(1, world))
     assert "error" not in line["gather"]["per_gpu_d2h"], line["gather"]["per_gpu_d2h"]
+    # tools/check_scale.py reads the line as it will read the driver's SCALE record, and names what a shared-GPU run gets
+    # wrong BY CONSTRUCTION: gloo instead of RCCL, every rank on the same GPU (the numbers it flags besides mean nothing here)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_scale
+    findings = " | ".join(check_scale.check_line(line))
+    assert "backend 'gloo'" in findings and "distinct GPUs" in findings, findings
+    assert "world_size_seen" not in findings and "per_rank has" not in findings, findings
 
 
 def test_bench_rccl_branch_with_one_rank():

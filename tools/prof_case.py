@@ -4,6 +4,7 @@
 CASE  track<seconds>[f]   `doppler track` replay of the synthetic ESTCUBE-1-like pass (rate=N: samples per second)
       config4r<rank>      that rank's chunk of BASELINE.json configs[4]: 1 h f32 -> i16 replay in 8 time chunks
       const<shift>        `doppler const --shift <shift>` (n=N samples, default 2^28)
+      copy                dpx_debug_copy of 1 GiB (calibration of the HBM-traffic counters: tools/profile_round.sh)
 keys  pair=i16:i16  variant=N (dpx_set_tuning)  cast=legacy  rate=N  iters=N  geom=BxV  and any dpx_options field
       (rows_r, walk_span, sub_lg ...).  tools/ab.py times several such cases against each other in one process."""
 import calendar
@@ -71,6 +72,14 @@ def launch(c, stream):
 
 if __name__ == "__main__":
     ctx = doppler_amd.Context(0)
+    if sys.argv[1] == "copy":
+        kv = dict(a.split("=") for a in sys.argv[2:])
+        a, b = torch.zeros(1 << 28, dtype=torch.int32, device="cuda:0"), torch.empty(1 << 28, dtype=torch.int32, device="cuda:0")
+        for _ in range(int(kv.get("iters", 5))):
+            ctx.debug_copy(a.data_ptr(), b.data_ptr(), 1 << 30, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        print("ran copy", 1 << 30)
+        sys.exit(0)
     c = make_case(ctx, sys.argv[1:])
     st = torch.cuda.current_stream()
     for _ in range(c["iters"]):

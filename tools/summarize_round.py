@@ -59,8 +59,9 @@ def main():
     rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
     import bench
     lines = ["# Round %s — rocprofv3 --kernel-trace --stats and HBM-traffic counters (1x MI355X, `tools/profile_round.sh %s`)" % (rnd[1:].lstrip("0"), rnd), "",
-             "Commands: `python bench.py --workload const --steps 20 --warmup 5 --no-cpu --no-extra` and `--workload track --steps 300` "
-             "(kernel trace; the two PMC passes of either workload: 20 steps); kernel sources sha `%s`." % bench.kernel_source_sha(), ""]
+             "Commands: `python bench.py --workload const --steps 20 --warmup 5 --no-cpu --no-extra` and `--workload track | track_256k | "
+             "config4_chunk --steps 300` (kernel trace; the two PMC passes of a workload: 20 steps); kernel sources sha `%s`.  A replay "
+             "workload launches W warm-up + K cold + ~150 ms of settling + K timed launches, all of them in the averages below." % bench.kernel_source_sha(), ""]
     result = {"kernel_source_sha": bench.kernel_source_sha()}
     # calibration of the counters on a copy of known size
     cal_f = counter(db_of(os.path.join(src, "cal_fetch")), "FETCH_SIZE", "max")
@@ -72,7 +73,10 @@ def main():
         wscale = (1 << 30) / (cal_w[ck[0]][1] * 1024.0)
         lines += ["Calibration on `dpx::copy_kernel` (1 GiB read + 1 GiB written): FETCH_SIZE x %.4f, WRITE_SIZE x %.4f "
                   "(the guide's gfx950 note: FETCH_SIZE reports half the bytes of a wide streaming read)." % (fscale, wscale), ""]
-    for wl, pat, alg in (("const", "rows_kernel", 268435456 * 8), ("track", "span_kernel", 614400000 * 8)):
+    for wl, pat, alg in (("const", "rows_kernel", 268435456 * 8), ("track", "span_kernel", 614400000 * 8),
+                         ("track_256k", "span_kernel", 153600000 * 8), ("config4_chunk", "tile_kernel", 460800000 * 12)):
+        if not db_of(os.path.join(src, wl + "_trace")):
+            continue
         stats = kernel_stats(db_of(os.path.join(src, wl + "_trace")))
         lines += ["## %s workload" % wl, "", "| kernel | calls | avg us | min us | max us | total us |", "|---|---|---|---|---|---|"]
         for n, c, a, mn, mx, t in stats[:6]:
@@ -88,14 +92,15 @@ def main():
                       "(%d B per launch) = %.1f %% of the 8.0 TB/s HBM3E peak." % (n, a, c, alg / a / 1e3, alg, alg / a / 1e3 / 80.0)]
             st = settled(db_of(os.path.join(src, wl + "_trace")), pat)
             if st:
+                # avg_launch_us_kernel_trace stays the average over ALL launches (bench.py: frac_rocprof); the settled subset
+                # is quoted beside it (frac_rocprof_settled), never instead of it
                 r["settled_launches"], r["settled_avg_us"], r["settled_median_us"] = st[0], round(st[1], 3), round(st[2], 3)
-                r["avg_launch_us_all_launches"] = r["avg_launch_us_kernel_trace"]
-                r["avg_launch_us_kernel_trace"] = round(st[1], 3)      # what bench.py quotes as frac_rocprof: the settled launches
                 lines += ["Launches that start more than 160 ms after the first one (%d of them: clocks settled, as in the bench line's "
                           "`extra.track`): average %.3f us, median %.3f us -> %.1f %% / %.1f %%." %
                           (st[0], st[1], st[2], alg / st[1] / 1e3 / 80.0, alg / st[2] / 1e3 / 80.0)]
-        f = counter(db_of(os.path.join(src, wl + "_fetch")), "FETCH_SIZE")
-        w = counter(db_of(os.path.join(src, wl + "_write")), "WRITE_SIZE")
+        have_pmc = db_of(os.path.join(src, wl + "_fetch")) and db_of(os.path.join(src, wl + "_write"))
+        f = counter(db_of(os.path.join(src, wl + "_fetch")), "FETCH_SIZE") if have_pmc else {}
+        w = counter(db_of(os.path.join(src, wl + "_write")), "WRITE_SIZE") if have_pmc else {}
         fk = [k for k in f if pat in k]
         if fk and fscale:
             rd = f[fk[0]][1] * 1024.0 * fscale
