@@ -12,7 +12,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-f
 
 LIB := $(LIBDIR)/libdoppler_hip.so
 API  := dpx_context dpx_resident dpx_operators dpx_plans dpx_stream
-OBJS := $(LIBDIR)/dpx_kernels.o $(API:%=$(LIBDIR)/%.o) $(LIBDIR)/dpx_planner.o $(LIBDIR)/orbit.o $(LIBDIR)/schedule.o
+OBJS := $(LIBDIR)/dpx_kernels.o $(API:%=$(LIBDIR)/%.o) $(LIBDIR)/dpx_planner.o $(LIBDIR)/dpx_simulate.o $(LIBDIR)/orbit.o $(LIBDIR)/schedule.o
 
 all: lib cli oracle cpptest
 
@@ -29,7 +29,7 @@ $(API:%=$(LIBDIR)/%.o): $(LIBDIR)/%.o: $(CSRC)/%.cpp $(CSRC)/dpx_internal.h $(CS
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
-$(LIBDIR)/dpx_planner.o: $(CSRC)/dpx_planner.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h
+$(LIBDIR)/dpx_planner.o $(LIBDIR)/dpx_simulate.o: $(LIBDIR)/%.o: $(CSRC)/%.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h
 	@mkdir -p $(LIBDIR)
 	g++ -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -c $< -o $@
 
@@ -57,9 +57,9 @@ tests/cpp/test_dsp: tests/cpp/test_dsp.cpp include/doppler_dsp.hpp include/doppl
 cpptest: tests/cpp/test_dsp
 
 # host-only fuzz of the planner under AddressSanitizer + UBSan (no GPU, no HIP)
-tests/cpp/test_planner_fuzz: tests/cpp/test_planner_fuzz.cpp $(CSRC)/dpx_planner.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h
+tests/cpp/test_planner_fuzz: tests/cpp/test_planner_fuzz.cpp $(CSRC)/dpx_planner.cpp $(CSRC)/dpx_simulate.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h
 	g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -ffp-contract=off -fno-fast-math -Wall \
-	    -o $@ tests/cpp/test_planner_fuzz.cpp $(CSRC)/dpx_planner.cpp
+	    -o $@ tests/cpp/test_planner_fuzz.cpp $(CSRC)/dpx_planner.cpp $(CSRC)/dpx_simulate.cpp
 
 planner-fuzz: tests/cpp/test_planner_fuzz
 	tests/cpp/test_planner_fuzz 300

@@ -11,7 +11,7 @@ import time
 import numpy as np
 import pytest
 
-from helpers import assert_same_bytes, make_iq
+from helpers import BPS, assert_same_bytes, load_golden, make_iq
 from test_gpu_parity import run_bulk
 
 pytestmark = pytest.mark.gpu
@@ -203,3 +203,75 @@ def test_four_processes_share_the_gpu_with_resident_kernels():
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for k, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("ok %d" % k) in o, "process %d:\n%s" % (k, o[-2000:])
+
+
+def test_async_blocks_whose_plan_wants_a_table(ctx, orc):
+    """dpx_shift_block_async with shifts whose period is below 4 — shift 0 (the reference resets the counter on EVERY sample:
+    period 1), samplerate / 2 (period 2), samplerate / 3 — and an ordinary shift between them: such a block's plan asks for
+    a corrector table, which the asynchronous slot has no room for; it takes the synchronous path inside the call (round 3
+    returned DPX_ERR_PLAN: a drop-in for the loop of main.rs:113-118 must take every input the loop takes).  Both block
+    formats, tickets in flight across the fallback, counters carried, against the oracle block by block."""
+    from doppler_amd import dsp
+    rate = 48000
+    shifts = [0.0, 5000.0, 24000.0, 0.0, 16000.0, -24000.0, 123.0, 0.0]
+    for intype, outtype, per in (("i16", "i16", 2048), ("f32", "i16", 1024), ("i16", "f32", 2048)):
+        x = make_iq(intype, per * len(shifts) - 100, 77)          # the last block is short
+        bs = 8192
+        sn, sn_w, tickets, got, want = 3, 3, [], [], []
+        for b, hz in enumerate(shifts):
+            blk = x[b * bs:(b + 1) * bs]
+            tk, sn = dsp.shift_block_async(blk, intype, outtype, sn, hz, rate, ctx=ctx)
+            w, _, _, sn_w = orc.shift_block(blk, intype, outtype, sn_w, hz, rate)
+            assert sn == sn_w, (b, hz)
+            want.append(w)
+            tickets.append(tk)
+            if len(tickets) == 3:
+                got.append(dsp.wait(tickets.pop(0), outtype, ctx=ctx))
+        while tickets:
+            got.append(dsp.wait(tickets.pop(0), outtype, ctx=ctx))
+        assert_same_bytes(np.concatenate(got), np.concatenate(want), outtype, "async blocks with tiny periods %s->%s" % (intype, outtype))
+
+
+def test_async_blocks_equal_the_synchronous_path_on_the_golden_track_replay(ctx, orc):
+    """dpx_shift_block_async / dpx_wait (the loop of main.rs:113-118 with block k + 1 read while block k is on the GPU): the
+    golden track replay block by block with two, then four blocks in flight — bytes and counters of the synchronous path
+    and of the golden file; a fifth outstanding ticket, a stale ticket and a short output buffer are refused."""
+    from doppler_amd import dsp
+    from doppler_amd.engine import DspError
+    t = load_golden("track_stream_case.npz")
+    rate = int(t["meta"][0])
+    x, want, log = t["x"], t["y"], t["shift_log"].astype(np.float32)
+    nb = (x.size + 8191) // 8192
+    assert nb == log.size
+    for depth in (2, 4):
+        sn, out, tickets = 0, [], []
+        for b in range(nb):
+            blk = x[b * 8192:(b + 1) * 8192]
+            tk, sn = dsp.shift_block_async(blk, "i16", "i16", sn, float(log[b]), rate, ctx=ctx)
+            tickets.append(tk)
+            if len(tickets) == depth:
+                out.append(dsp.wait(tickets.pop(0), "i16", ctx=ctx))
+        while tickets:
+            out.append(dsp.wait(tickets.pop(0), "i16", ctx=ctx))
+        assert_same_bytes(np.concatenate(out), want, "i16", "async blocks, %d in flight" % depth)
+        sn_sync = 0
+        for b in range(nb):
+            _, _, sn_sync = dsp.shift_block(x[b * 8192:(b + 1) * 8192], "i16", "i16", sn_sync, float(log[b]), rate, ctx=ctx)
+        assert sn == sn_sync
+    # f32 -> f32 and an empty block
+    xf = make_iq("f32", 1024, 5)
+    tk, sn = dsp.shift_block_async(xf, "f32", "f32", 7, -15000.0, 256000, ctx=ctx)
+    tk0, sn0 = dsp.shift_block_async(xf[:0], "f32", "f32", sn, -15000.0, 256000, ctx=ctx)
+    w, _, _, sn_w = orc.shift_block(xf, "f32", "f32", 7, -15000.0, 256000)
+    assert_same_bytes(dsp.wait(tk, "f32", ctx=ctx), w, "f32", "async f32 block")
+    assert dsp.wait(tk0, "f32", ctx=ctx).size == 0 and sn0 == sn == sn_w
+    # misuse
+    ts = [dsp.shift_block_async(xf, "f32", "f32", 0, 1.0, 48000, ctx=ctx)[0] for _ in range(4)]
+    with pytest.raises(DspError):
+        dsp.shift_block_async(xf, "f32", "f32", 0, 1.0, 48000, ctx=ctx)
+    with pytest.raises(DspError):
+        dsp.wait(ts[0] + 100, "f32", ctx=ctx)
+    for tk in ts:
+        dsp.wait(tk, "f32", ctx=ctx)
+    with pytest.raises(DspError):
+        dsp.wait(ts[0], "f32", ctx=ctx)
