@@ -30,6 +30,8 @@
 
 namespace dpx {
 
+static_assert(kLargeQuickEnd == kThetaHuge, "the planner's path bounds (dpx_types.h) are those of the device sincos (dpx_sincos.h)");
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 

@@ -193,9 +193,9 @@ static void emit(PlanResult &plan, uint64_t first, uint64_t count, float ratio, 
         s.n_large = plan.segs.back().n_large;
         s.n_huge = plan.segs.back().n_huge;
     } else {
-        s.n_plain = first_counter_reaching(ratio, 0x39800000u);     // 2^-12
-        s.n_large = first_counter_reaching(ratio, 0x42f00000u);     // 120
-        s.n_huge = first_counter_reaching(ratio, 0x4e800000u);      // 2^30 (dpx_sincos.h, kLargeQuickEnd)
+        s.n_plain = first_counter_reaching(ratio, kThetaPlain);     // 2^-12
+        s.n_large = first_counter_reaching(ratio, kThetaLarge);     // 120
+        s.n_huge = first_counter_reaching(ratio, kThetaHuge);       // 2^29 (dpx_sincos.h, kLargeQuickEnd)
     }
     s.pad = 0;
     s.first = first;

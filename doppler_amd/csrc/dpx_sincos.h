@@ -29,7 +29,7 @@
 //     a wave-uniform branch): quadrant reduction (4 instructions: the rounding is a
 //     fused multiply-add against 1.5 * 2^52) + the two polynomials and nothing
 //     else — no range selects, no clamps;
-//   * every active lane in [120, 2^30) — all a stream produces beyond 120, since
+//   * every active lane in [120, 2^29) — all a stream produces beyond 120, since
 //     |theta| < 2^26: the remainder of x * 2/pi from a three-term 2/pi in double
 //     precision (7 instructions; rounds 1-3: glibc's 32x96-bit integer product,
 //     31 instructions).  Not glibc's operation sequence — its RESULT, proved over
@@ -81,7 +81,7 @@ __device__ __forceinline__ double mad(double a, double b, double c)
 // the CPU model (tests/extended/sincos_model.c) and on the device (tests/extended/exhaustive_device_sincos.py): 0 mismatches.
 constexpr double kTwoOverPi = 0x1.45F306DC9C883p-1;        // 2/pi rounded to double: glibc's hpi_inv / 2^24
 constexpr double kRoundMagic = 0x1.8p52;                   // 1.5 * 2^52: ulp 1, room for |n| < 2^31
-constexpr uint32_t kLargeQuickEnd = 0x4e800000u;           // 2^30: where reduce_large_quick's proof ends (DevSeg::n_huge)
+constexpr uint32_t kLargeQuickEnd = 0x4e000000u;           // 2^29: where the quick reductions' proofs end (DevSeg::n_huge)
 template <bool FMA>
 __device__ __forceinline__ double reduce_small(double x, uint32_t &n_out)
 {
@@ -93,7 +93,7 @@ __device__ __forceinline__ double reduce_small(double x, uint32_t &n_out)
     else               return x - nd * HPI;
 }
 
-// 120 <= |x| < 2^30 (round 4): the remainder of x * 2/pi from a three-term 2/pi in double precision instead of glibc's
+// 120 <= |x| < 2^30 (round 4; since round 5 the SSE2 build's fast path only, and used below 2^29): the remainder of x * 2/pi from a three-term 2/pi in double precision instead of glibc's
 // 32x96-bit integer product (reduce_large below: 31 instructions; this: 7, the conversion included).
 //   n  = round(x * 2/pi)                 as above (|n| < 2^30: the magic sum is exact to the integer)
 //   r  = x*c1 - n                        c1 = the leading 29 bits of 2/pi: 24 x 29 bits, the product and the difference exact
@@ -118,8 +118,29 @@ __device__ __forceinline__ double reduce_large_quick(double x, uint32_t &n_out)
     return r * HPI;
 }
 
-// the two polynomials on the reduced argument, then quadrant signs and the sin/cos exchange.
-// glibc: argument * sign[sidx&3] with sign = {+,-,-,+}; table[1] (sidx&2) is -cos; odd quadrants trade places.
+// quadrant signs and the sin/cos exchange on the two float results (glibc: argument * sign[sidx&3] with sign = {+,-,-,+};
+// table[1] (sidx&2) is -cos; odd quadrants trade places): seven instructions.
+__device__ __forceinline__ void sincos_signs(uint32_t fs, uint32_t fc, uint32_t quad, uint32_t sidx, float &rs, float &rc)
+{
+    // sign flips: fs ^= ((sidx + 1) & 2) << 30, fc ^= (sidx & 2) << 30 — one three-input bit operation each
+    // (bitop3 0x6c = b ^ (a & c)); odd quadrant: the two trade places — a bit-field insert under an all-ones /
+    // all-zeros mask, without a compare, its wait states and the condition register.  Spelled as instructions: the
+    // compiler otherwise splits them into and / xor / or chains (12 instructions instead of 7).
+    const uint32_t t = sidx << 30;                       // bit 31 = sidx & 2
+    const uint32_t t1 = t + 0x40000000u;                 // bit 31 = (sidx + 1) & 2
+    const uint32_t sign = 0x80000000u;
+    uint32_t m;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6c" : "=v"(fs) : "v"(t1), "v"(fs), "s"(sign));
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6c" : "=v"(fc) : "v"(t), "v"(fc), "s"(sign));
+    asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m) : "v"(quad));                 // -1 if the quadrant is odd
+    uint32_t rsb, rcb;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(rsb) : "v"(m), "v"(fc), "v"(fs));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(rcb) : "v"(m), "v"(fs), "v"(fc));
+    rs = __uint_as_float(rsb);
+    rc = __uint_as_float(rcb);
+}
+
+// the two polynomials on the reduced argument in glibc's own operation order (the general path, and the SSE2 build)
 template <bool FMA>
 __device__ __forceinline__ void sincos_poly(double xr, uint32_t quad, uint32_t sidx, float &rs, float &rc)
 {
@@ -137,24 +158,62 @@ __device__ __forceinline__ void sincos_poly(double xr, uint32_t quad, uint32_t s
     const double x6 = x4 * x2;
     const double s = mad<FMA>(x3, S1, xr);
     const double c = mad<FMA>(x4, C2, c1);
-    uint32_t fs = __float_as_uint((float)mad<FMA>(x5, s1, s));
-    uint32_t fc = __float_as_uint((float)mad<FMA>(x6, c2, c));
-    // sign flips: fs ^= ((sidx + 1) & 2) << 30, fc ^= (sidx & 2) << 30 — one three-input bit operation each
-    // (bitop3 0x6c = b ^ (a & c)); odd quadrant: the two trade places — a bit-field insert under an all-ones /
-    // all-zeros mask, without a compare, its wait states and the condition register.  Spelled as instructions: the
-    // compiler otherwise splits them into and / xor / or chains (12 instructions instead of 7).
-    const uint32_t t = sidx << 30;                       // bit 31 = sidx & 2
-    const uint32_t t1 = t + 0x40000000u;                 // bit 31 = (sidx + 1) & 2
-    const uint32_t sign = 0x80000000u;
-    uint32_t m;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6c" : "=v"(fs) : "v"(t1), "v"(fs), "s"(sign));
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6c" : "=v"(fc) : "v"(t), "v"(fc), "s"(sign));
-    asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m) : "v"(quad));                 // -1 if the quadrant is odd
-    uint32_t rsb, rcb;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(rsb) : "v"(m), "v"(fc), "v"(fs));
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(rcb) : "v"(m), "v"(fs), "v"(fc));
-    rs = __uint_as_float(rsb);
-    rc = __uint_as_float(rcb);
+    sincos_signs(__float_as_uint((float)mad<FMA>(x5, s1, s)), __float_as_uint((float)mad<FMA>(x6, c2, c)), quad, sidx, rs, rc);
+}
+
+// ---- round 5: the two polynomials in 9 operations instead of glibc's 12, for the FMA build's two fast paths.
+// glibc evaluates  sin = (x + x3*S1) + x5*(S2 + x2*S3)  and  cos = ((C0 + x2*C1) + x4*C2) + x6*(C3 + x2*C4)  (twelve double
+// operations with x2 ... x6).  Horner's rule needs nine:
+//     sin = x + x * (x2 * (S1 + x2*(S2 + x2*S3)))          cos = C0 + x2*(C1 + x2*(C2 + x2*(C3 + x2*C4)))
+// The two differ in the last places of the DOUBLE result, and the float result only changes when the double lies within
+// those last places of a float rounding boundary.  Whether that ever happens is a finite question, and it is answered
+// by enumeration, not by an error bound: for every argument of [2^-12, 120) (remainder as glibc forms it) and of
+// [120, 2^29) (remainder from reduce_large_two), both signs, the two floats are those of the restated glibc sincosf —
+// 316 669 952 + 371 195 904 arguments, 0 mismatches (tests/extended/sincos_model.c, part of the CPU suite; the device
+// itself: tests/extended/exhaustive_device_sincos.py -> profiles/r05_exhaustive_device_sincos.json).  Ten other
+// associations of the same polynomials were enumerated as well and none of them ever differs (profiles/r05_sincos.md):
+// the function's float results are far more robust than its operation order suggests.
+// One corrector: 25 -> 22 instructions in [2^-12, 120), 28 -> 24 in [120, 2^29).
+__device__ __forceinline__ void sincos_horner(double xr, uint32_t n, float &rs, float &rc)
+{
+    constexpr double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5,
+                     C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+    constexpr double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7,
+                     S3 = -0x1.994eb3774cf24p-13;
+    const double x2 = xr * xr;
+    const double u = __builtin_fma(x2, __builtin_fma(x2, S3, S2), S1);
+    const double sn = __builtin_fma(xr, x2 * u, xr);
+    const double h = __builtin_fma(x2, __builtin_fma(x2, C4, C3), C2);
+    const double cs = __builtin_fma(x2, __builtin_fma(x2, h, C1), C0);
+    sincos_signs(__float_as_uint((float)sn), __float_as_uint((float)cs), n, n, rs, rc);
+}
+
+// The same on the remainder r of x * 2/pi itself (|r| <= 1/2): glibc multiplies its remainder by pi/2 and evaluates the
+// polynomials above; here pi/2 is inside the coefficients — SPk = Sk * hpi^(2k+1), CPk = Ck * hpi^(2k), hpi = glibc's double
+// pi/2, each product formed exactly (rational arithmetic) and rounded once — and the multiplication is gone.
+//     sin = r * (SP0 + r2*(SP1 + r2*(SP2 + r2*SP3)))       cos = 1 + r2*(CP1 + r2*(CP2 + r2*(CP3 + r2*CP4)))
+__device__ __forceinline__ void sincos_horner_quadrants(double r, uint32_t n, float &rs, float &rc)
+{
+    constexpr double SP0 = 0x1.921fb54442d18p+0, SP1 = -0x1.4abbbf2376856p-1, SP2 = 0x1.466031025d4cdp-4, SP3 = -0x1.2dd0472562ec7p-8;
+    constexpr double CP1 = -0x1.3bd3cc7ec2ba7p+0, CP2 = 0x1.03c1decc70af8p-2, CP3 = -0x1.55c6643b8d8a8p-6, CP4 = 0x1.d9f7bc1fcaa24p-11;
+    const double r2 = r * r;
+    const double w = __builtin_fma(r2, __builtin_fma(r2, __builtin_fma(r2, SP3, SP2), SP1), SP0);
+    const double sn = r * w;
+    const double h = __builtin_fma(r2, __builtin_fma(r2, CP4, CP3), CP2);
+    const double cs = __builtin_fma(r2, __builtin_fma(r2, h, CP1), 1.0);
+    sincos_signs(__float_as_uint((float)sn), __float_as_uint((float)cs), n, n, rs, rc);
+}
+
+// 120 <= |x| < 2^29: the remainder of x * 2/pi in quadrants from TWO terms of 2/pi (c1 = its leading 29 bits: x*c1 - n
+// exact; c2 = the next 53).  The third term of reduce_large_quick matters for one magnitude of the whole range up to 2^30,
+// 0x4e4dc501 (8.6e8) — beyond 2^29, and a stream's |theta| stays below 2^26 — so the quick range ends at 2^29 since round 5.
+__device__ __forceinline__ double reduce_large_two(double x, uint32_t &n_out)
+{
+    constexpr double C1 = 0x1.45F306Dp-1, C2 = 0x1.9391054A7F09Dp-30;
+    const double pm = __builtin_fma(x, kTwoOverPi, kRoundMagic);
+    n_out = (uint32_t)__double2loint(pm);
+    const double nd = pm - kRoundMagic;
+    return __builtin_fma(x, C2, __builtin_fma(x, C1, -nd));
 }
 
 // |y| >= 120: exact 32x96-bit fixed-point product with 4/pi (glibc reduce_large).
@@ -211,16 +270,22 @@ __device__ __forceinline__ void sincosf_glibc(float y, float &sn, float &cs)
     if (__builtin_amdgcn_ballot_w64(!plain) == 0) {
         uint32_t n;
         const double xr = reduce_small<FMA>((double)y, n);
-        sincos_poly<FMA>(xr, n, n, sn, cs);
+        if constexpr (FMA) sincos_horner(xr, n, sn, cs);
+        else               sincos_poly<FMA>(xr, n, n, sn, cs);
         return;
     }
-    // 120 <= |y| < 2^30: every lane takes the three-term double-precision reduction
+    // 120 <= |y| < 2^29: every lane takes the quick double-precision reduction
     // (the common case for a stream: theta = 2 pi ratio n passes 120 after a few thousand counters, and stays below 2^26)
     const bool large = (ax - 0x42f00000u) < (kLargeQuickEnd - 0x42f00000u);
     if (__builtin_amdgcn_ballot_w64(!large) == 0) {
         uint32_t n;
-        const double xr = reduce_large_quick((double)y, n);
-        sincos_poly<FMA>(xr, n, n, sn, cs);
+        if constexpr (FMA) {
+            const double r = reduce_large_two((double)y, n);
+            sincos_horner_quadrants(r, n, sn, cs);
+        } else {
+            const double xr = reduce_large_quick((double)y, n);
+            sincos_poly<FMA>(xr, n, n, sn, cs);
+        }
         return;
     }
     sincosf_general<FMA>(y, sn, cs);
@@ -378,7 +443,7 @@ __device__ __forceinline__ void corrector(float ratio, uint32_t n, float &c, flo
 typedef float sc_f32x2 __attribute__((ext_vector_type(2)));
 // path: what the caller knows about all the counters of the WAVEFRONT (a wavefront-uniform value; DevSeg's n_plain /
 // n_large / n_huge give it for free): kPathPlain — every |theta| in [2^-12, 120); kPathLarge — every |theta| in
-// [120, 2^30); kPathAny — nothing known, the function looks and votes.
+// [120, 2^29); kPathAny — nothing known, the function looks and votes.
 constexpr int kPathAny = 0, kPathPlain = 1, kPathLarge = 2;
 
 template <bool FMA>
@@ -434,17 +499,22 @@ __device__ __forceinline__ void corrector4_f(float ratio, sc_f32x2 f01, sc_f32x2
             uint32_t q;
             float sn, c;
             const double xr = reduce_small<FMA>((double)th[k], q);
-            sincos_poly<FMA>(xr, q, q, sn, c);
+            if constexpr (FMA) sincos_horner(xr, q, sn, c);
+            else               sincos_poly<FMA>(xr, q, q, sn, c);
             cs[k] = sc_f32x2{c, sn};
         }
     } else if (all_large) {
-        // every |theta| in [120, 2^30)
+        // every |theta| in [120, 2^29)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             uint32_t q;
             float sn, c;
-            const double xr = reduce_large_quick((double)th[k], q);
-            sincos_poly<FMA>(xr, q, q, sn, c);
+            if constexpr (FMA) {
+                sincos_horner_quadrants(reduce_large_two((double)th[k], q), q, sn, c);
+            } else {
+                const double xr = reduce_large_quick((double)th[k], q);
+                sincos_poly<FMA>(xr, q, q, sn, c);
+            }
             cs[k] = sc_f32x2{c, sn};
         }
     } else {

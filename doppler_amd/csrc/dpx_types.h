@@ -29,12 +29,15 @@ struct DevSeg {
     uint32_t flags;
     // |theta(n)| never decreases with the counter n (every rounding in fl32(-2 pi * fl32(ratio * fl32(n))) is monotone), so
     // the range of sincosf's argument paths is three counters, found on the host by bisection with the same f32 products:
-    // the first n whose |theta| bits reach 2^-12 / 120 / 2^30 (0xffffffff: none).  A tile whose counters lie inside
+    // the first n whose |theta| bits reach kThetaPlain / kThetaLarge / kThetaHuge = 2^-12 / 120 / 2^29 (0xffffffff: none).  A tile whose counters lie inside
     // [n_plain, n_large) or [n_large, n_huge) knows its path from two scalar comparisons (dpx_sincos.h, corrector4_f).
     uint32_t n_plain, n_large, n_huge;
     uint32_t pad;
 };
 static_assert(sizeof(DevSeg) == 64, "DevSeg is read with scalar loads");
+// float bit patterns of the |theta| bounds of sincosf's fast paths (dpx_sincos.h): [2^-12, 120) and [120, 2^29) are the two
+// ranges over which the device's cheaper operation sequences are proved, by enumeration, to give glibc's floats
+constexpr uint32_t kThetaPlain = 0x39800000u, kThetaLarge = 0x42f00000u, kThetaHuge = 0x4e000000u;
 
 constexpr uint32_t kSegRows = 2u;        // (most of) this stretch is served by a rows-kernel launch
 constexpr uint32_t kSegTileTable = 4u;   // lut_off / c0 / tmod describe a tile-kernel table
