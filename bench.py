@@ -190,7 +190,7 @@ def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True, w
         alg = n * (bi + bo)
         frac = lambda ms: round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         prof = profiled(which) if world == 1 else None
-        by_tiles = (it, ot) == ("f32", "i16") and layout.get("f32_i16_by_tiles")
+        by_tiles = it != ot and layout.get("f32_i16_by_tiles")            # the mixed pairs of a many-matrix plan run on the tile kernel
         roof = {"bound": "hbm", "achieved": round(alg / (kms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": frac(kms), "frac_cold": frac(kms_cold),
                 "frac_is": "K launches after %d ms of untimed launches (settled clocks); frac_cold: K launches right after the W warm-up "

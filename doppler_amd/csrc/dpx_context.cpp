@@ -165,13 +165,16 @@ int run_plan(const dpx::PlanResult &plan, const DevPlan &dev, const void *d_in, 
     // (128x2 75 / 75).
     dpx::LaunchGeom g = g_in;
     g.sub_lg = plan.sub_lg;
+    const std::vector<dpx::Launch> &launches = dpx::launches_for(plan, in_fmt, out_fmt);
     if (g.autosel && g.tile() == 1024u) {
-        const bool wide = out_fmt == DPX_FMT_F32 || plan.tile_tables;
+        // (tile tables were laid out for the tile ranges of the DEFAULT launch list: the whole-stream alternative of the
+        // mixed pairs evaluates nearly everything per sample and takes the per-sample shapes)
+        const bool wide = out_fmt == DPX_FMT_F32 || (plan.tile_tables && &launches == &plan.launches);
         g.block = wide ? 256 : in_fmt == DPX_FMT_I16 ? 64 : 128;
         g.vecs = wide ? 1 : in_fmt == DPX_FMT_I16 ? 4 : 2;
     }
     if (g.block == 64 && !(in_fmt == DPX_FMT_I16 && out_fmt == DPX_FMT_I16)) { g.block = 128; g.vecs = 2; }   // 64 x 4 exists for i16 -> i16 only
-    for (const dpx::Launch &ln : dpx::launches_for(plan, in_fmt, out_fmt)) {
+    for (const dpx::Launch &ln : launches) {
         int rc;
         if (ln.kind == 0)
             rc = dpx::launch_rows(d_in, in_fmt, d_out, out_fmt, dev.segs, dev.lut, ln.rows, fma, g.legacy_cast, st);

@@ -1324,15 +1324,15 @@ static int rows_t(const void *d_in, void *d_out, const DevSeg *d_segs, const voi
     const uint64_t M = ((1ull << (31 + s)) + cols - 1) / cols;
     const dim3 grid((uint32_t)(n_main + n_extra));
     const float2 *tab = lut + r.tab_off;
-    // table or evaluation: the plan allows both for long periods, the formats decide (dpx_planner.cpp, kRowsComputeMinP)
-    const bool comp = r.compute == 2 || (r.compute == 1 && IN_FMT == DPX_FMT_I16 && OUT_FMT == DPX_FMT_I16);
+    // table or evaluation (dpx_planner.cpp, kRowsComputeMinP): since round 5 the same choice for every format pair
+    const bool comp = r.compute != 0;
 #define DPX_ROWS_CASE(RR, CC)                                                                                                               \
     if (r.R == RR && comp == CC) {                                                                                                           \
         if (fma) rows_kernel<IN_FMT, OUT_FMT, true, RR, CC><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_extra, r.P, r.ratio, r.idx0, d_segs, r);  \
         else     rows_kernel<IN_FMT, OUT_FMT, false, RR, CC><<<grid, kRowsLanes, 0, st>>>(in, out, tab, r.A, r.L, cols, M, sh, (uint32_t)n_extra, r.P, r.ratio, r.idx0, d_segs, r); \
         return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                                                      \
     }
-    DPX_ROWS_CASE(2, false) DPX_ROWS_CASE(4, false) DPX_ROWS_CASE(8, false) DPX_ROWS_CASE(4, true) DPX_ROWS_CASE(8, true)
+    DPX_ROWS_CASE(2, false) DPX_ROWS_CASE(4, false) DPX_ROWS_CASE(8, false) DPX_ROWS_CASE(4, true) DPX_ROWS_CASE(8, true) DPX_ROWS_CASE(2, true)
 #undef DPX_ROWS_CASE
     return DPX_ERR_ARG;
 }

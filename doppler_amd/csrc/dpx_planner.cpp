@@ -312,32 +312,38 @@ uint32_t pick_row_length(uint32_t P, uint64_t body, uint32_t R, const PlanTuning
     return best;
 }
 
-// rows per wavefront: 2 while one period of correctors stays L1/L2-hot, 4 for large tables
-// (measured, GB/s at R = 2 / 4 / 8: 8 KB table 6615 / 6264 / 6194; 876 KB table 5406 / 5660 / 5777)
+// rows per wavefront, and table or evaluation.
 // Rows of 8192 or 16384 samples (the two rows of a wavefront 32 or 64 KiB apart) run 3 points faster than any other
-// length (83.7 / 84.3 % against 80.1-81.7 % for L = 4096 ... 131072 with the headline's own table: `tools/ab.py --set
-// rowlen`), which needs a period that divides 16384.  Every other period pays, on top, for its table: one period is read by
-// every wavefront of the launch, 8 bytes per R samples beside the 8 bytes of stream an i16 -> i16 sample moves.  From
-// kRowsComputeMinP on such a launch may instead let every wavefront evaluate its columns' correctors itself, once for its
-// 4 rows: P = 5120 / 6400 / 10 240 / 20 480 / 1 024 000: +1.0 / +1.1 / +1.4 / +1.5 / +3.5 points for i16 -> i16, no gain
-// for the pairs with an f32 side (16 or 12 bytes of stream per sample; profiles/r02_walk.md section 7).  The plan does not
-// know the formats, so such a launch carries both — the table and (ratio, idx0) — and launch_rows picks per format pair.
+// length (83.7 / 84.3 % against 80.1-81.7 % for L = 4096 ... 131072 with the headline's own table), which needs a period
+// that divides 16384.  Every other period pays, on top, for its table: one period is read by every wavefront of the launch,
+// 8 bytes per R samples beside the 8-16 bytes of stream a sample moves.  From kRowsComputeMinP on a launch lets every
+// wavefront evaluate its columns' correctors itself, once for its rows, while the rows' loads are in flight.
+// Round 5: with the sincos at 22-24 instructions (dpx_sincos.h) that is TWO rows per wavefront and every format pair —
+// one box, same process (profiles/raw/r05_ab_rows_eval.log), table under 4 rows (round 4's default) / evaluation under 4 /
+// under 2:   3 Hz (P = 1 024 000): i16->i16 71.3 / 76.5 / 80.2 %, f32->f32 71.5 / 72.7 / 80.4, i16->f32 70.5 / 72.0 / 80.3,
+// f32->i16 75.2 / 75.2 / 82.3;   100 Hz (P = 10 240): i16->i16 - / 80.2 / 82.7, f32->f32 79.9 / 78.7 / 81.6, i16->f32 77.7 /
+// 78.5 / 80.5, f32->i16 82.6 / 83.5 / 85.6;   9876.543 Hz (P = 2592): 80.5 -> 83.8.  (Rounds 2-4, sincos at 31-52
+// instructions: four rows, i16 -> i16 only.)  Short periods keep their table: P = 480 at large angles 81.5 % against 76.7
+// evaluated; the headline (P = 1024, an 8 KiB table, rows of 8 periods) stays on its table as well — evaluation measured
+// +1 point there on a warm chip, but a kernel whose rate does not depend on the shader clock is the safer headline.
+// The launch still carries both — the table and (ratio, idx0) — so that `rows_compute` can A/B them.
 constexpr uint32_t kRowsComputeMinP = 2049;
 
-// 0: table only; 1: i16 -> i16 evaluates, the other pairs read the table; 2: every pair evaluates (measurement)
+// 0: the launch reads its table; 2: every wavefront evaluates its columns' correctors
 uint32_t rows_compute(uint32_t P, const PlanTuning &tn)
 {
     if (P < 4) return 0;
     if (tn.rows_compute == 1) return 2;
-    return P >= (tn.rows_compute ? tn.rows_compute : kRowsComputeMinP) ? 1 : 0;
+    return P >= (tn.rows_compute ? tn.rows_compute : kRowsComputeMinP) ? 2 : 0;
 }
 
 uint32_t pick_rows_per_wave(uint32_t P, const PlanTuning &tn, uint32_t compute)
 {
+    // tables: 2 rows while one period of correctors stays L1/L2-hot, 4 for large tables (measured, GB/s at R = 2 / 4 / 8:
+    // 8 KB table 6615 / 6264 / 6194; 876 KB table 5406 / 5660 / 5777); evaluation: 2 (above)
     uint32_t R = ((uint64_t)P + 3) * 8 <= (128u << 10) ? 2 : 4;
-    if (compute) R = 4;                                    // measured best for both ways (tables of such periods: 2 -> 4 is +1)
+    if (compute) R = 2;
     if (tn.rows_r) R = tn.rows_r;                          // measurement override
-    if (compute && R == 2) R = 4;                          // the evaluating kernel is built for 4 and 8 rows
     return (R == 2 || R == 4 || R == 8) ? R : 2;
 }
 
@@ -479,7 +485,7 @@ bool walk_waves_ok(uint32_t waves, bool uni)
 
 const std::vector<Launch> &launches_for(const PlanResult &plan, int in_fmt, int out_fmt)
 {
-    return (in_fmt == 1 && out_fmt == 0 && !plan.whole_tiles.empty()) ? plan.whole_tiles : plan.launches;
+    return (in_fmt != out_fmt && !plan.whole_tiles.empty()) ? plan.whole_tiles : plan.launches;
 }
 
 bool span_launch_shape(const WalkArgs &w, int in_fmt, int out_fmt, SpanLaunch *o)
@@ -537,7 +543,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         uint32_t comp = rows_compute(s.period, tn);
         *R = pick_rows_per_wave(s.period, tn, comp);
         *L = pick_row_length(s.period, end - *A, *R, tn);
-        if (comp == 1 && *L != 0 && *L % 8192 == 0 && *L <= 16384) {       // the fast row lengths: table, two rows
+        if (comp != 0 && tn.rows_compute != 1 && *L != 0 && *L % 8192 == 0 && *L <= 16384) {       // the fast row lengths: table, two rows
             comp = 0;
             *R = pick_rows_per_wave(s.period, tn, 0);
             *L = pick_row_length(s.period, end - *A, *R, tn);
@@ -825,7 +831,7 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
         pos = std::max(pos, c.hi);
     }
     add_tiles(pos, plan.n_samples);
-    // launches_for(): the alternative of a many-matrix plan for f32 -> i16
+    // launches_for(): the alternative of a many-matrix plan for f32 -> i16 and i16 -> f32
     if (choice == kChooseAuto && plan.n_samples != 0) {
         bool many = false;
         for (const Launch &ln : plan.launches) many = many || (ln.kind == 2 && ln.walk.uni.n_spans == 0);

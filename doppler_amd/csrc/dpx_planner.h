@@ -84,7 +84,7 @@ struct PlanResult {
     std::vector<uint32_t> hint;      // stretch index per 2^kHintShift samples
     std::vector<TableBuild> tables;
     std::vector<Launch> launches;
-    // f32 -> i16 only: ONE tile launch over the whole stream, filled when `launches` holds a span launch of many matrices
+    // f32 -> i16 and i16 -> f32: ONE tile launch over the whole stream, filled when `launches` holds a span launch of many matrices
     // (track mode) and the kernel choice is the planner's own — see launches_for()
     std::vector<Launch> whole_tiles;
     // span-kernel launch (at most one per plan), each list closed by a sentinel
@@ -116,11 +116,13 @@ void finalize(PlanResult &plan, uint32_t tile, int choice /* KernelChoice */, co
 bool walk_waves_ok(uint32_t waves, bool uni);
 
 // The launches of a finalized plan for one format pair (DPX_FMT_*: 0 = i16, 1 = f32): `plan.launches`, except that a
-// plan of many matrices (one span launch driven by descriptors: track mode) runs f32 -> i16 through the tile kernel alone,
-// every corrector evaluated per sample.  With 12 bytes per sample that arithmetic hides behind the memory side, and the
-// tile kernel's one-shot kilobyte tiles in address order stream better than eight-wavefront spans whose rows change lanes
-// through LDS: 300 s replay 79.6-80.4 % against 75.8-78.1 % of the HBM peak on four boxes of five (-1.3 on the fifth;
-// profiles/r04_walk.md section 5).  The other pairs, and one-matrix launches of this pair, tie or prefer the span kernel.
+// plan of many matrices (one span launch driven by descriptors: track mode) runs the two MIXED pairs through the tile
+// kernel alone, every corrector evaluated per sample.  With 12 bytes per sample that arithmetic hides behind the memory
+// side, and the tile kernel's one-shot kilobyte tiles in address order stream better than spans whose rows are 8 bytes
+// per sample on one side and 4 on the other: 300 s replays, same process, tile against span kernel — f32 -> i16 78.8 / 76.6 %
+// (round 4: 79.6-80.4 against 75.8-78.1 on four boxes of five), i16 -> f32 77.6 / 74.1 % since round 5's cheaper sincos
+// (round 4: a tie, 72-75); f32 -> f32 stays on the span kernel (80.1 against 78.4), i16 -> i16 by far (80.0 against 70.7)
+// (profiles/raw/r05_ab_route_poly9.log).  One-matrix launches of the mixed pairs tie or prefer the span kernel.
 // dpx_run_device and simulate() both take their launches from here.
 const std::vector<Launch> &launches_for(const PlanResult &plan, int in_fmt, int out_fmt);
 

@@ -85,10 +85,9 @@ struct RowsArgs {
     uint32_t n_segs;
     uint32_t R;          // rows per workgroup: 2, 4 or 8
     uint32_t P;          // period of the stretch (L is a multiple of it)
-    // compute != 0: the launch MAY leave the table alone — every wavefront then evaluates the correctors of its 64 x S
-    // columns itself, once for its R rows (R = 4: a quarter of a sincos per sample), while the rows' loads are in flight.
-    // For periods whose table does not stay in the CUs' vector caches (the planner's kRowsComputeMinP); 1: launch_rows
-    // does so for i16 -> i16, 2: for every format pair (measurement).
+    // compute != 0: the launch leaves the table alone — every wavefront evaluates the correctors of its 64 x S
+    // columns itself, once for its R rows (R = 2: half a sincos per sample), while the rows' loads are in flight.
+    // For periods whose table does not stay in the CUs' vector caches (the planner's kRowsComputeMinP).
     uint32_t compute;
     uint32_t idx0;       // counter of sample A, minus one: column c uses counter ((idx0 + c) mod P) + 1
     float ratio;

@@ -25,9 +25,9 @@ typedef struct dpx_options {
     uint32_t rows_mult;      /* rows kernel: row length = rows_mult * lcm(period, 4) samples */
     uint32_t rows_maxl;      /* rows kernel: longest row considered */
     uint32_t rows_r;         /* rows kernel: rows per wavefront (2, 4 or 8) */
-    uint32_t rows_compute;   /* rows kernel: for periods of at least this many samples an i16 -> i16 launch leaves the table alone,
-                              * its wavefronts evaluate their columns' correctors (0 = the planner's threshold, 0xffffffff = never,
-                              * 1 = always and for every format pair) */
+    uint32_t rows_compute;   /* rows kernel: for periods of at least this many samples a launch leaves its table alone, every wavefront
+                              * evaluates its columns' correctors once for its rows (0 = the planner's threshold, 2049;
+                              * 0xffffffff = never; 1 = always) */
     uint32_t walk_waves;     /* span kernel: wavefronts per workgroup (2, 4, 5 or 8) */
     uint32_t walk_span;      /* span kernel: most rows of a matrix one workgroup keeps its column window for.  0 = the planner's
                               * own cut: spans of 8, a matrix of up to 12 rows whole, several adjacent windows per workgroup for
@@ -79,7 +79,7 @@ typedef struct dpx_layout {
     uint32_t n_stretches;
     uint32_t rows_launches, tile_launches, walk_launches;
     uint32_t walk_matrices, walk_workgroups, leftover_ranges, leftover_workgroups;
-    uint32_t f32_i16_by_tiles;  /* 1: an f32 -> i16 run of this plan is ONE tile-kernel launch over the whole stream instead of
+    uint32_t f32_i16_by_tiles;  /* 1: an f32 -> i16 or i16 -> f32 run of this plan is ONE tile-kernel launch over the whole stream instead of
                                  * the launches counted above (plans of many matrices: csrc/dpx_planner.h, launches_for) */
     uint32_t reserved;
 } dpx_layout;
