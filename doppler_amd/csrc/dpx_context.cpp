@@ -164,7 +164,6 @@ int run_plan(const dpx::PlanResult &plan, const DevPlan &dev, const void *d_in, 
     // f32 -> f32 256x1 78 / 78 (128x2 76 / 76); f32 -> i16 128x2 78.5 / 79.5 (256x1 79.5 / 75.5); i16 -> f32 256x1 80 / 76
     // (128x2 75 / 75).
     dpx::LaunchGeom g = g_in;
-    g.sub_lg = plan.sub_lg;
     const std::vector<dpx::Launch> &launches = dpx::launches_for(plan, in_fmt, out_fmt);
     if (g.autosel && g.tile() == 1024u) {
         // (tile tables were laid out for the tile ranges of the DEFAULT launch list: the whole-stream alternative of the

@@ -1270,29 +1270,21 @@ static int tiles_t(const void *d_in, void *d_out, const DevSeg *d_segs, uint32_t
     const float2 *lut = static_cast<const float2 *>(d_lut);
     if (t.n_tiles == 0) return DPX_OK;
     if (t.n_tiles > 0x7fffffffull) return DPX_ERR_ARG;
-    // sub-launches of about 2^sub_lg samples each (see span_t): a tile launch is cut by tile index on the host
-    const uint64_t n_all = t.n_tiles, lo_all = t.tile_lo;
-    const uint32_t pieces = sub_launch_pieces(n_all * g.tile(), g.sub_lg);
-    const uint64_t per = (n_all + pieces - 1) / pieces;
-    for (uint64_t off = 0; off < n_all; off += per) {
-        t.tile_lo = lo_all + off;
-        t.n_tiles = n_all - off < per ? n_all - off : per;
-        const dim3 grid((uint32_t)t.n_tiles);
+    // (one launch whatever the length: cutting a tile launch into sub-launches as span_t does changes nothing here —
+    // configs[4]'s chunk 77.7 / 77.9 / 77.4 % as one, two, four launches, the per-sample path 62.8 / 62.5: profiles/raw/r05_ab_sub_tiles.log)
+    const dim3 grid((uint32_t)t.n_tiles);
 #define DPX_CASE(B, Vv)                                                                                      \
-        if (g.block == B && g.vecs == Vv) {                                                                  \
-            if (fma) tile_kernel<IN_FMT, OUT_FMT, true, B, Vv><<<grid, B, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t);  \
-            else     tile_kernel<IN_FMT, OUT_FMT, false, B, Vv><<<grid, B, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t); \
-            if (hipGetLastError() != hipSuccess) return DPX_ERR_HIP;                                         \
-            continue;                                                                                        \
-        }
-        DPX_CASE(128, 2) DPX_CASE(256, 1)
-        if constexpr (IN_FMT == DPX_FMT_I16 && OUT_FMT == DPX_FMT_I16) {       // one wavefront x 16 samples per lane: built for this pair only
-            DPX_CASE(64, 4)
-        }
-#undef DPX_CASE
-        return DPX_ERR_ARG;
+    if (g.block == B && g.vecs == Vv) {                                                                      \
+        if (fma) tile_kernel<IN_FMT, OUT_FMT, true, B, Vv><<<grid, B, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t);  \
+        else     tile_kernel<IN_FMT, OUT_FMT, false, B, Vv><<<grid, B, 0, st>>>(in, out, d_segs, n_segs, d_hint, lut, t); \
+        return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;                                       \
     }
-    return DPX_OK;
+    DPX_CASE(128, 2) DPX_CASE(256, 1)
+    if constexpr (IN_FMT == DPX_FMT_I16 && OUT_FMT == DPX_FMT_I16) {       // one wavefront x 16 samples per lane: built for this pair only
+        DPX_CASE(64, 4)
+    }
+#undef DPX_CASE
+    return DPX_ERR_ARG;
 }
 
 int launch_tiles(const void *d_in, int in_fmt, void *d_out, int out_fmt, const DevSeg *d_segs,

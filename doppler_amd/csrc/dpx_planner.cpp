@@ -516,7 +516,6 @@ void finalize(PlanResult &plan, uint32_t tile, int choice, const PlanTuning &tn)
 {
     const uint64_t kWalkTileMin = tn.walk_tilemin ? tn.walk_tilemin : kWalkTileMinDefault;
     plan.tile = tile;
-    plan.sub_lg = tn.sub_lg;
     plan.error = nullptr;
     plan.tables.clear();
     plan.launches.clear();

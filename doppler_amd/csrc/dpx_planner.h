@@ -62,7 +62,7 @@ struct PlanTuning {
                                  // most that many rows, one window per workgroup, two rows per wavefront per turn
     uint32_t walk_flags = 0;     // bit 0: a one-matrix span launch reads descriptors like any other (measurement of what the
                                  // descriptor load costs); bits 8..: row-length target in KiSamples (measurement)
-    uint32_t sub_lg = 0;         // span and tile launches are dealt out in pieces of about 2^sub_lg samples (0 = kSubLaunchLg,
+    uint32_t sub_lg = 0;         // span launches are dealt out in pieces of about 2^sub_lg samples (0 = kSubLaunchLg,
                                  // >= 48 = never cut)
     bool operator==(const PlanTuning &o) const
     {
@@ -79,7 +79,6 @@ struct PlanResult {
     // filled by finalize():
     uint64_t lut_entries = 0;        // size of the corrector-table pool, in (cos, sin) entries
     uint32_t tile = 0;               // tile-kernel samples per workgroup the tables were laid out for
-    uint32_t sub_lg = 0;             // PlanTuning::sub_lg, for the tile launches (span launches carry it in WalkArgs)
     bool tile_tables = false;        // some stretch is served from a tile-kernel table
     std::vector<uint32_t> hint;      // stretch index per 2^kHintShift samples
     std::vector<TableBuild> tables;

@@ -63,7 +63,6 @@ struct LaunchGeom {
     int vecs;     // 4-sample groups per lane: 1 or 2
     int autosel = 0;   // the caller set neither: 128 x 2 or 256 x 1 (the same 1024-sample tile) is chosen per launch
     int legacy_cast = 0;   // dpx_set_i16_cast(DPX_CAST_LEGACY_X86): i16 output wraps instead of saturating (every kernel: a launch-uniform flag)
-    uint32_t sub_lg = 0;   // tile launches are dealt out in pieces of about 2^sub_lg samples (0: kSubLaunchLg)
     uint32_t tile() const { return (uint32_t)block * kSamplesPerLane * (uint32_t)vecs; }
 };
 

@@ -35,7 +35,7 @@ typedef struct dpx_options {
                               * that many rows, one window per workgroup, two rows per wavefront per turn */
     uint32_t walk_flags;     /* bit 0: a span launch of ONE matrix reads its descriptors from memory like a many-matrix launch instead
                               * of taking the matrix from its kernel arguments; bits 8..: row-length target in KiSamples */
-    uint32_t sub_lg;         /* span and tile launches over long streams are dealt out as sub-launches of about 2^sub_lg samples, back
+    uint32_t sub_lg;         /* span launches over long streams are dealt out as sub-launches of about 2^sub_lg samples, back
                               * to back on the stream (0 = the default, 28: 1 GiB of i16; >= 48 = one launch whatever the length) */
     uint64_t walk_tilemin;   /* span plans: uncovered gaps at least this long (samples) get a tile-kernel launch */
 } dpx_options;

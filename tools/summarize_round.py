@@ -83,8 +83,14 @@ def main():
             lines.append("| `%s` | %d | %.3f | %.3f | %.3f | %.1f |" % (n, c, a, mn, mx, t))
         main_k = [s for s in stats if pat in s[0]]
         r = {"algorithmic_bytes_per_launch": alg}
+        # a span launch over a long stream is dealt out as sub-launches of ~2^28 samples (csrc/dpx_types.h, sub_launch_pieces):
+        # "per launch" below is per RUN OF THE PLAN — the kernel's dispatches are added up in groups of `pieces`
+        n_samples = alg // (8 if wl != "config4_chunk" else 12)
+        pieces = max(1, (n_samples + (1 << 27)) >> 28) if pat == "span_kernel" else 1
+        r["sub_launches"] = pieces
         if main_k:
             n, c, a, mn, mx, t = main_k[0]
+            c, a, mn, mx = c // pieces, a * pieces, mn * pieces, mx * pieces
             r["kernel"] = n
             r["avg_launch_us_kernel_trace"] = round(a, 3)
             r["launches"] = c
@@ -92,6 +98,7 @@ def main():
                       "(%d B per launch) = %.1f %% of the 8.0 TB/s HBM3E peak." % (n, a, c, alg / a / 1e3, alg, alg / a / 1e3 / 80.0)]
             st = settled(db_of(os.path.join(src, wl + "_trace")), pat)
             if st:
+                st = (st[0] // pieces, st[1] * pieces, st[2] * pieces)
                 # avg_launch_us_kernel_trace stays the average over ALL launches (bench.py: frac_rocprof); the settled subset
                 # is quoted beside it (frac_rocprof_settled), never instead of it
                 r["settled_launches"], r["settled_avg_us"], r["settled_median_us"] = st[0], round(st[1], 3), round(st[2], 3)
@@ -103,8 +110,8 @@ def main():
         w = counter(db_of(os.path.join(src, wl + "_write")), "WRITE_SIZE") if have_pmc else {}
         fk = [k for k in f if pat in k]
         if fk and fscale:
-            rd = f[fk[0]][1] * 1024.0 * fscale
-            wr = w[fk[0]][1] * 1024.0 * wscale
+            rd = f[fk[0]][1] * 1024.0 * fscale * pieces
+            wr = w[fk[0]][1] * 1024.0 * wscale * pieces
             r.update(fetch_size_raw_kib=round(f[fk[0]][1], 1), write_size_raw_kib=round(w[fk[0]][1], 1), fetch_scale=fscale, write_scale=wscale,
                      hbm_read_bytes_per_launch=int(rd), hbm_write_bytes_per_launch=int(wr), hbm_bytes_per_launch=int(rd + wr))
             lines += ["", "HBM traffic per launch (separate --pmc passes, calibrated): %.1f MiB read + %.1f MiB written = %.1f MiB "
