@@ -2,7 +2,8 @@
 # One rocprofv3 --kernel-trace --stats run per row of DESIGN.md's kernel table (tools/prof_case.py, ITERS launches each,
 # back to back); prints a markdown table of the kernels' median / average / best duration per launch and the algorithmic
 # GB/s they mean.  The first ~50-100 ms after idle run at ramping clocks (profiles/r02_walk.md), which is what separates
-# the average from the median on the arithmetic-heavy rows.
+# the average from the median on the arithmetic-heavy rows.  A plan whose span launch is cut into sub-launches (long streams)
+# counts as ONE launch per run: its sub-launches' durations are added up.
 set -u
 REPO=$PWD
 export TMPDIR=/tmp
@@ -17,9 +18,9 @@ row() {   # label bytes_per_sample case [opts...]
   rm -rf /tmp/tr; mkdir -p /tmp/tr; cd /tmp
   rocprofv3 --kernel-trace --stats -d /tmp/tr -o run -- python $REPO/tools/prof_case.py "$@" iters=$ITERS > /tmp/tr/log 2>&1
   cd $REPO
-  python - "$label" $bps <<'PY' >> $OUTMD
+  python - "$label" $bps $ITERS <<'PY' >> $OUTMD
 import glob, sqlite3, sys, re
-label, bps = sys.argv[1], int(sys.argv[2])
+label, bps, iters = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 db = glob.glob("/tmp/tr/**/*.db", recursive=True)
 m = re.search(r"^ran .* (\d+)$", open("/tmp/tr/log").read(), re.M)
 n = int(m.group(1)) if m else 0
@@ -29,7 +30,9 @@ c = sqlite3.connect(db[0])
 names = [r[0] for r in c.execute("select name, count(*) from kernels where name like '%dpx::%' group by name having count(*) >= 10 order by sum(duration) desc")]
 per = {}
 for nm in names:
-    per[nm] = [r[0] / 1e3 for r in c.execute("select duration from kernels where name = ? order by start", (nm,))]
+    d = [r[0] / 1e3 for r in c.execute("select duration from kernels where name = ? order by start", (nm,))]
+    g = len(d) // iters if iters and len(d) % iters == 0 else 1     # a long span launch is dealt out as g sub-launches per run of the plan
+    per[nm] = [sum(d[i * g:(i + 1) * g]) for i in range(len(d) // g)]
 k = min(len(v) for v in per.values())
 tot = [sum(per[nm][i] for nm in names) for i in range(k)]           # a plan may be two launches: add them per run
 tot_sorted = sorted(tot)
