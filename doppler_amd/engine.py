@@ -77,7 +77,9 @@ class Context:
         check(self._lib.dpx_set_options(self._h, _lib.make_options(opts)))
 
     def set_resident(self, on=True):
-        """The resident block kernel behind shift_block / shift_block_async (default on); off: a launch per block."""
+        """The resident block kernel behind shift_block / shift_block_async (default on); off: a launch per block.
+        While it is resident (until 2 ms after the last block) launches of OTHER software on this device — torch in the same
+        process — may queue behind it: turn it off where the device is shared with such work."""
         check(self._lib.dpx_set_resident(self._h, 1 if on else 0))
 
     def resident_stats(self):

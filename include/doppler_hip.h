@@ -121,10 +121,11 @@ int dpx_shift_blocks(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt, 
  *     dpx_shift_block_async(ctx, blk[k+1], ...&t[k+1]);  dpx_wait(ctx, t[k], out, ...);  write(out);
  * Tickets complete in the order they were issued; at most four may be outstanding (DPX_ERR_PLAN beyond that).  Blocks of
  * up to 8192 samples (the reference's block is 2048 / 1024); every input dpx_shift_block takes is taken.
- * Round 4: the blocks of both calls go to a RESIDENT kernel (one workgroup per staging buffer polling a doorbell in the
- * buffer; it leaves when idle for 2 ms or when the context launches anything else), so a block costs PCIe round trips,
- * not a launch: 12.7 us per 8 KiB block alone, 3.2 us with four in flight (a launch per block: 17.9 / 10.0 us;
- * profiles/r04_cli.md).  DPX_RESIDENT=0 in the environment restores a launch per block. */
+ * The blocks of both calls go to a RESIDENT kernel (one workgroup per staging buffer polling a doorbell in the buffer; it
+ * leaves when idle for 2 ms or when the library launches anything else on that device; at most one per device and process —
+ * contexts hand it over), so a block costs PCIe round trips, not a launch: 12.7 us per 8 KiB block alone, 3.2 us with four
+ * in flight (a launch per block: 17.9 / 10.0 us; profiles/r04_cli.md).  DPX_RESIDENT=0 in the environment restores a launch
+ * per block; INTEGRATION.md section 3d says what sharing a device with other GPU software means for it. */
 typedef uint32_t dpx_ticket;
 int dpx_shift_block_async(dpx_ctx *ctx, const void *in, size_t in_bytes, int in_fmt, int out_fmt, uint32_t *samplenum,
                           float shift_hz, uint32_t samplerate, dpx_ticket *ticket);
