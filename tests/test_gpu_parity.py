@@ -470,6 +470,38 @@ def test_span_kernel_one_matrix_launch(ctx, orc, span, flags):
         ctx.set_tuning(0, 0, 3)
 
 
+@pytest.mark.parametrize("sub_lg", [12, 17, 21])
+def test_span_launches_dealt_out_as_sub_launches(ctx, orc, sub_lg):
+    """Round 5: a span launch over a long stream is dealt out as sub-launches of about 2^28 samples, back to back on the stream
+    (csrc/dpx_kernels.hip, span_t: workgroups find their work from (offset + blockIdx)).  dpx_options.sub_lg makes the pieces
+    small enough to exercise the cut on test-sized streams — hundreds of sub-launches, cuts inside spans' padding, between
+    spans and leftover groups, and in the leftover rows of a one-matrix launch — for every format pair, descriptor-driven
+    (track-shaped) and one-matrix (const mode) launches: the bytes are those of the oracle, i.e. of the uncut launch."""
+    import doppler_amd
+    rng = np.random.default_rng(5 + sub_lg)
+    track = ([(120000 + 2048 * int(rng.integers(0, 9)), float(np.float32(rng.uniform(-9000, 9000)))) for _ in range(12)], 256000, 3)
+    const = ([((1 << 21) + 4321, 5001.0)], 1024000, 12345)
+    ctx.set_options(sub_lg=sub_lg)
+    try:
+        for variant, (segs, rate, sn0) in ((3, track), (5, const)):
+            ctx.set_tuning(0, 0, variant)
+            lay = doppler_amd.plan_layout(segs, rate, sn0, variant=variant)
+            assert lay["walk_launches"] == 1 and (lay["walk_matrices"] >= 8 if variant == 3 else lay["walk_matrices"] == 1), lay
+            n = sum(c for c, _ in segs)
+            assert n >> sub_lg >= 2                       # really more than one piece
+            for intype, outtype in (("i16", "i16"), ("f32", "i16"), ("i16", "f32"), ("f32", "f32")):
+                if variant == 3 and intype != outtype:
+                    continue                              # (the mixed pairs of a many-matrix plan run on the tile kernel)
+                x = make_iq(intype, n, 7000 + sub_lg, full_scale=True)
+                want, sn = oracle_segments(orc, x, intype, outtype, segs, rate, sn0)
+                got, fin = run_bulk(ctx, x, intype, outtype, segs, rate, sn0=sn0)
+                assert fin == sn
+                assert_same_bytes(got, want, outtype, "sub-launches of 2^%d, variant %d, %s->%s" % (sub_lg, variant, intype, outtype))
+    finally:
+        ctx.set_options()
+        ctx.set_tuning(0, 0, 3)
+
+
 @pytest.mark.parametrize("rows_compute,rows_r", [(1, 0), (1, 8), (0, 0), (0xffffffff, 0)])
 def test_rows_kernel_evaluates_its_correctors(ctx, orc, rows_compute, rows_r):
     """Rows launches that leave their table alone: every wavefront evaluates the correctors of its columns for its 4 (8)

@@ -116,7 +116,7 @@ def main():
                      hbm_read_bytes_per_launch=int(rd), hbm_write_bytes_per_launch=int(wr), hbm_bytes_per_launch=int(rd + wr))
             lines += ["", "HBM traffic per launch (separate --pmc passes, calibrated): %.1f MiB read + %.1f MiB written = %.1f MiB "
                       "against %.1f MiB algorithmic: ratio %.4f (reads alone against the input bytes: %.4f)." %
-                      (rd / 2**20, wr / 2**20, (rd + wr) / 2**20, alg / 2**20, (rd + wr) / alg, rd / (alg / 2)), ""]
+                      (rd / 2**20, wr / 2**20, (rd + wr) / 2**20, alg / 2**20, (rd + wr) / alg, rd / (alg * (8 / 12 if wl == "config4_chunk" else 0.5))), ""]
         result[wl] = r
     with open(os.path.join(out, "%s_rocprof_kernel_stats.md" % rnd), "w") as fh:
         fh.write("\n".join(lines) + "\n")
