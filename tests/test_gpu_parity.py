@@ -470,7 +470,7 @@ def test_span_kernel_one_matrix_launch(ctx, orc, span, flags):
         ctx.set_tuning(0, 0, 3)
 
 
-@pytest.mark.parametrize("sub_lg", [12, 17, 21])
+@pytest.mark.parametrize("sub_lg", [12, 16, 19])
 def test_span_launches_dealt_out_as_sub_launches(ctx, orc, sub_lg):
     """Round 5: a span launch over a long stream is dealt out as sub-launches of about 2^28 samples, back to back on the stream
     (csrc/dpx_kernels.hip, span_t: workgroups find their work from (offset + blockIdx)).  dpx_options.sub_lg makes the pieces
