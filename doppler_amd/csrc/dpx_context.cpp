@@ -312,7 +312,7 @@ int dpx_set_options(dpx_ctx *ctx, const dpx_options *opt)
 {
     if (!ctx) return fail(DPX_ERR_ARG, "ctx is null");
     if (opt) {
-        if (opt->rows_r != 0 && opt->rows_r != 2 && opt->rows_r != 4 && opt->rows_r != 8) return fail(DPX_ERR_ARG, "rows_r must be 2, 4 or 8");
+        if (opt->rows_r != 0 && opt->rows_r != 2 && opt->rows_r != 4) return fail(DPX_ERR_ARG, "rows_r must be 2 or 4");
         const uint32_t ww = opt->walk_waves;
         if (ww != 0 && !dpx::walk_waves_ok(ww, false)) return fail(DPX_ERR_ARG, "walk_waves must be 2, 4, 5 or 8");
         if (opt->walk_span == 1 || opt->walk_span > 4096) return fail(DPX_ERR_ARG, "walk_span must be 0 (the planner's cut) or 2..4096 rows");

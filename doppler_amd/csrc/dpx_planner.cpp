@@ -344,7 +344,7 @@ uint32_t pick_rows_per_wave(uint32_t P, const PlanTuning &tn, uint32_t compute)
     uint32_t R = ((uint64_t)P + 3) * 8 <= (128u << 10) ? 2 : 4;
     if (compute) R = 2;
     if (tn.rows_r) R = tn.rows_r;                          // measurement override
-    return (R == 2 || R == 4 || R == 8) ? R : 2;
+    return (R == 2 || R == 4) ? R : 2;
 }
 
 struct Interval { uint64_t lo, hi; };

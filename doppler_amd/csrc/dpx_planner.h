@@ -52,7 +52,7 @@ enum KernelChoice {
 struct PlanTuning {
     uint32_t rows_mult = 0;      // rows kernel: row length = rows_mult * lcm(period, 4)
     uint32_t rows_maxl = 0;      // rows kernel: longest row considered
-    uint32_t rows_r = 0;         // rows kernel: rows per wavefront (2, 4 or 8)
+    uint32_t rows_r = 0;         // rows kernel: rows per wavefront (2 or 4)
     uint32_t walk_waves = 0;     // span kernel: wavefronts per workgroup (2, 4, 5 or 8)
     uint32_t rows_compute = 0;   // rows kernel: periods from this many samples on are evaluated in the kernel (0 = the
                                  // planner's default, 0xffffffff = never, 1 = always)

@@ -255,6 +255,31 @@ __device__ __forceinline__ double reduce_large(uint32_t xi, uint32_t &quad, uint
     return __builtin_fma((double)rem_hi, 4294967296.0, (double)lo) * PI63;
 }
 
+// A wavefront whose lanes lie in BOTH fast ranges, or below 2^-12 (round 5): a tile in which the counter wraps from the end
+// of a period (|theta| in the thousands) to 1, 2, 3 ... — one tile in 25-75 of a replay's per-sample launches, and it went
+// through sincosf_general (the integer product for every lane beyond 120: ~75 instructions per corrector).  Here the quadrant
+// rounding is shared, both remainders are formed — glibc's own x - n*pi/2 below 120, (x*c1 - n + x*c2) * pi/2 from 120 on —
+// one is selected per lane, and Horner's polynomials in radians follow: 32 instructions, valid for |y| < 2^29 (tiny lanes:
+// sin = y, cos = 1 as in glibc).  Enumerated like the other paths (tests/extended/sincos_model.c --mixed): every argument of
+// [0, 2^29), both signs, 0 mismatches against the restated glibc; FMA build only.
+__device__ __forceinline__ void sincosf_mixed(float y, float &sn, float &cs)
+{
+    constexpr double C1 = 0x1.45F306Dp-1, C2 = 0x1.9391054A7F09Dp-30, HPI = 0x1.921FB54442D18p0;
+    const uint32_t ax = __float_as_uint(y) & 0x7fffffffu;
+    const double x = (double)y;
+    const double pm = __builtin_fma(x, kTwoOverPi, kRoundMagic);
+    const uint32_t n = (uint32_t)__double2loint(pm);
+    const double nd = pm - kRoundMagic;
+    const double xs = __builtin_fma(-nd, HPI, x);
+    const double xl = __builtin_fma(x, C2, __builtin_fma(x, C1, -nd)) * HPI;
+    const double xr = ax < 0x42f00000u ? xs : xl;
+    float rs, rc;
+    sincos_horner(xr, n, rs, rc);
+    const bool tiny = ax < 0x39800000u;
+    sn = tiny ? y : rs;
+    cs = tiny ? 1.0f : rc;
+}
+
 template <bool FMA>
 __device__ __forceinline__ void sincosf_general(float y, float &sn, float &cs);
 
@@ -287,6 +312,12 @@ __device__ __forceinline__ void sincosf_glibc(float y, float &sn, float &cs)
             sincos_poly<FMA>(xr, n, n, sn, cs);
         }
         return;
+    }
+    if constexpr (FMA) {
+        if (__builtin_amdgcn_ballot_w64(!(ax < kLargeQuickEnd)) == 0) {      // both fast ranges and tiny lanes in one wavefront
+            sincosf_mixed(y, sn, cs);
+            return;
+        }
     }
     sincosf_general<FMA>(y, sn, cs);
 }
@@ -444,7 +475,7 @@ typedef float sc_f32x2 __attribute__((ext_vector_type(2)));
 // path: what the caller knows about all the counters of the WAVEFRONT (a wavefront-uniform value; DevSeg's n_plain /
 // n_large / n_huge give it for free): kPathPlain — every |theta| in [2^-12, 120); kPathLarge — every |theta| in
 // [120, 2^29); kPathAny — nothing known, the function looks and votes.
-constexpr int kPathAny = 0, kPathPlain = 1, kPathLarge = 2;
+constexpr int kPathAny = 0, kPathPlain = 1, kPathLarge = 2, kPathMixed = 3;   // (kPathMixed: found by the vote only)
 
 template <bool FMA>
 __device__ __forceinline__ void corrector4_f(float ratio, sc_f32x2 f01, sc_f32x2 f23, sc_f32x2 cs[4], int path = kPathAny);
@@ -492,6 +523,7 @@ __device__ __forceinline__ void corrector4_f(float ratio, sc_f32x2 f01, sc_f32x2
         // every |theta| in [2^-12, 120)  (nan / inf have the largest magnitudes: they fail the upper bound)
         all_plain = __builtin_amdgcn_ballot_w64(!(lo >= 0x39800000u && hi < 0x42f00000u)) == 0;
         all_large = !all_plain && __builtin_amdgcn_ballot_w64(!(lo >= 0x42f00000u && hi < kLargeQuickEnd)) == 0;
+        if (FMA && !all_plain && !all_large && __builtin_amdgcn_ballot_w64(!(hi < kLargeQuickEnd)) == 0) path = kPathMixed;
     }
     if (all_plain) {
 #pragma unroll
@@ -515,6 +547,14 @@ __device__ __forceinline__ void corrector4_f(float ratio, sc_f32x2 f01, sc_f32x2
                 const double xr = reduce_large_quick((double)th[k], q);
                 sincos_poly<FMA>(xr, q, q, sn, c);
             }
+            cs[k] = sc_f32x2{c, sn};
+        }
+    } else if (FMA && path == kPathMixed) {
+        // lanes on both sides of 120 (a counter wrapping inside the tile) or below 2^-12, none beyond 2^29
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float sn, c;
+            sincosf_mixed(th[k], sn, c);
             cs[k] = sc_f32x2{c, sn};
         }
     } else {

@@ -68,7 +68,7 @@ struct LaunchGeom {
 
 // One rows-kernel launch: a tabulated periodic stretch processed as a matrix whose
 // rows are L samples long (L a multiple of the period and of 4), so that a column
-// always sees the same corrector.  A workgroup (one wavefront) takes R (2, 4 or 8)
+// always sees the same corrector.  A workgroup (one wavefront) takes R (2 or 4)
 // consecutive rows x 64 lanes x S samples; column slices of one row group are
 // consecutive workgroups, so the grid sweeps HBM contiguously.
 // Workgroups past n_rg * cols evaluate the ragged ranges [r0, A) and [B, r1)
@@ -82,7 +82,7 @@ struct RowsArgs {
     uint32_t tab_off;    // table-pool entry index of the (P + 3)-entry table (origin: sample A)
     uint32_t seg_lo;     // index of the stretch holding r0
     uint32_t n_segs;
-    uint32_t R;          // rows per workgroup: 2, 4 or 8
+    uint32_t R;          // rows per workgroup: 2 or 4
     uint32_t P;          // period of the stretch (L is a multiple of it)
     // compute != 0: the launch leaves the table alone — every wavefront evaluates the correctors of its 64 x S
     // columns itself, once for its R rows (R = 2: half a sincos per sample), while the rows' loads are in flight.

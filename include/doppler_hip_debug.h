@@ -24,7 +24,7 @@ extern "C" {
 typedef struct dpx_options {
     uint32_t rows_mult;      /* rows kernel: row length = rows_mult * lcm(period, 4) samples */
     uint32_t rows_maxl;      /* rows kernel: longest row considered */
-    uint32_t rows_r;         /* rows kernel: rows per wavefront (2, 4 or 8) */
+    uint32_t rows_r;         /* rows kernel: rows per wavefront (2 or 4) */
     uint32_t rows_compute;   /* rows kernel: for periods of at least this many samples a launch leaves its table alone, every wavefront
                               * evaluates its columns' correctors once for its rows (0 = the planner's threshold, 2049;
                               * 0xffffffff = never; 1 = always) */

@@ -10,6 +10,7 @@
  * argument by argument with the same IEEE double operations the device executes (fma, add, mul, conversion):
  *     sincos_model [--v 0|1] [--plain] [--lo BITS] [--hi BITS]
  *       default: the large range, |y| in [120, 2^29), both signs: quick reduction vs the integer path
+ *       --mixed: |y| in [0, 2^29), the path of wavefronts whose lanes lie in both fast ranges (sincosf_mixed; FMA build)
  *       --plain: |y| in [2^-12, 120): rounding by fused multiply-add against 1.5*2^52 vs glibc's truncating conversion
  *       --v:     libm build (1 = FMA contraction, 0 = SSE2)
  * Exit status 0 iff there is no mismatch.  tests/test_oracle.py runs all four enumerations (about 20 s on 8 cores);
@@ -72,19 +73,25 @@ static double quick_plain(float y,int v,float*sn,float*cs){
     if(v) horner(xr,n,sn,cs); else poly(v,xr,n,n,sn,cs);
     return fabs(xr);
 }
+// mixed: shared quadrant rounding, both remainders, one selected per lane, Horner in radians; tiny lanes sin = y, cos = 1
+static void mixed(float y,float*sn,float*cs){
+    double x=y; uint32_t ax=fb(y)&0x7fffffffu; double pm=__builtin_fma(x,C,MAGIC); uint32_t n=(uint32_t)db(pm); double nd=pm-MAGIC;
+    double xs=__builtin_fma(-nd,HPI,x); double xl=__builtin_fma(x,c2,__builtin_fma(x,c1,-nd))*HPI;
+    horner(ax<0x42f00000u?xs:xl,n,sn,cs);
+    if(ax<0x39800000u){ *sn=y; *cs=1.0f; } }
 typedef struct { uint32_t lo,hi; int v,mode; uint64_t n,mism; double max_ok_xr, min_bad_xr; uint32_t bads[16]; } job_t;
 static void *work(void*a){ job_t*j=a; j->min_bad_xr=10;
   for(uint64_t u=j->lo;u<j->hi;++u){ for(int sg=0;sg<2;++sg){ uint32_t b=(uint32_t)u|(sg?0x80000000u:0); float y;memcpy(&y,&b,4);
     float es,ec; orc_sincosf_glibc235(y,&es,&ec,j->v); float qs,qc; double axr=0;
-    if(j->mode==0) quick_large(y,j->v,&qs,&qc); else axr=quick_plain(y,j->v,&qs,&qc);
+    if(j->mode==0) quick_large(y,j->v,&qs,&qc); else if(j->mode==2) mixed(y,&qs,&qc); else axr=quick_plain(y,j->v,&qs,&qc);
     int bad = fb(qs)!=fb(es)||fb(qc)!=fb(ec); j->n++;
     if(bad){ if(j->mism<16) j->bads[j->mism]=b; j->mism++; if(axr<j->min_bad_xr)j->min_bad_xr=axr; } else if(axr>j->max_ok_xr) j->max_ok_xr=axr;
   }} return 0; }
 int main(int argc,char**argv){ uint32_t lo=0x42f00000u,hi=0x4e000000u; int v=1,nt=8,mode=0;
-  for(int i=1;i<argc;++i){ if(!strcmp(argv[i],"--v"))v=atoi(argv[++i]); else if(!strcmp(argv[i],"--lo"))lo=strtoul(argv[++i],0,0); else if(!strcmp(argv[i],"--hi"))hi=strtoul(argv[++i],0,0); else if(!strcmp(argv[i],"--plain"))mode=1; }
+  for(int i=1;i<argc;++i){ if(!strcmp(argv[i],"--v"))v=atoi(argv[++i]); else if(!strcmp(argv[i],"--lo"))lo=strtoul(argv[++i],0,0); else if(!strcmp(argv[i],"--hi"))hi=strtoul(argv[++i],0,0); else if(!strcmp(argv[i],"--plain"))mode=1; else if(!strcmp(argv[i],"--mixed")){mode=2;lo=0;hi=0x4e000000u;v=1;} }
   pthread_t th[64]; job_t jb[64]; memset(jb,0,sizeof jb); uint64_t span=hi-lo;
   for(int t=0;t<nt;++t){ jb[t].lo=lo+span*t/nt; jb[t].hi=lo+span*(t+1)/nt; jb[t].v=v; jb[t].mode=mode; pthread_create(&th[t],0,work,&jb[t]); }
   uint64_t n=0,m=0; double mx=0,mn=10;
   for(int t=0;t<nt;++t){ pthread_join(th[t],0); n+=jb[t].n; m+=jb[t].mism; if(jb[t].max_ok_xr>mx)mx=jb[t].max_ok_xr; if(jb[t].min_bad_xr<mn)mn=jb[t].min_bad_xr; for(uint64_t k=0;k<jb[t].mism&&k<16;++k) printf("  bad %08x\n",jb[t].bads[k]); }
-  printf("mode=%s v=%d range %08x..%08x n=%llu mismatches=%llu  max|xr| among ok=%.17g (pi/4=%.17g) min|xr| among bad=%.17g\n",mode?"plain":"large",v,lo,hi,(unsigned long long)n,(unsigned long long)m,mx,M_PI/4,mn);
+  printf("mode=%s v=%d range %08x..%08x n=%llu mismatches=%llu  max|xr| among ok=%.17g (pi/4=%.17g) min|xr| among bad=%.17g\n",mode==2?"mixed":mode?"plain":"large",v,lo,hi,(unsigned long long)n,(unsigned long long)m,mx,M_PI/4,mn);
   return m!=0; }

@@ -126,7 +126,7 @@ def test_rows_launches_that_evaluate_their_correctors(orc):
              ([(1 << 21, 160.0)], 1024000, 3001), ([(600000, 250.0), (3000000, 50.0)], 1024000, 5)]
     for segs, rate, sn0 in cases:
         want, _ = oracle_counters(orc, segs, rate, sn0)
-        for opts in (dict(), dict(rows_compute=1), dict(rows_compute=1, rows_r=8), dict(rows_compute=0xffffffff), dict(rows_compute=5000)):
+        for opts in (dict(), dict(rows_compute=1), dict(rows_compute=1, rows_r=4), dict(rows_compute=0xffffffff), dict(rows_compute=5000)):
             lay = doppler_amd.plan_layout(segs, rate, sn0, 128, 2, 6, options=opts)
             assert lay["rows_launches"] == len(segs), (segs, opts, lay)
             c, w = doppler_amd.plan_simulate(segs, rate, sn0, 128, 2, 6, options=opts)

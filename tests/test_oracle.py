@@ -79,7 +79,7 @@ def test_device_reductions_proved_by_enumeration_on_the_cpu_model(tmp_path):
                            os.path.join(ROOT, "tests", "extended", "sincos_model.c"), os.path.join(ROOT, "oracle", "sincosf_glibc.c"),
                            "-lm", "-lpthread"])
     for args in (["--v", "1"], ["--v", "0"], ["--plain", "--v", "1", "--lo", "0x39800000", "--hi", "0x42f00000"],
-                 ["--plain", "--v", "0", "--lo", "0x39800000", "--hi", "0x42f00000"]):
+                 ["--plain", "--v", "0", "--lo", "0x39800000", "--hi", "0x42f00000"], ["--mixed"]):
         r = subprocess.run([exe] + args, capture_output=True, text=True)
         assert r.returncode == 0 and "mismatches=0 " in r.stdout, r.stdout + r.stderr
 
