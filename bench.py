@@ -115,15 +115,16 @@ REPLAYS = {
                       "doppler track -s 1024000 -i f32 -o i16, 1 h replay: rank 3 of 8's time chunk (460.8 M samples, counter seeded from "
                       "the closed form): one GPU's share of BASELINE.json configs[4]"),
 }
+SUSTAIN_S = 2.5      # headline: seconds of back-to-back launches after the timed region (roofline.frac_sustained)
 SETTLE_S = 0.15     # untimed launches before the settled measurement of a secondary workload (clocks: profiles/r02_walk.md)
 
 
 def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True, which="track"):
     """Secondary workloads (never the default `value`): `track` = BASELINE.json configs[2] at N=1 and configs[4] sharded at
     N>1; `track_256k` and `config4_chunk` (N=1 only) are the replays the kernels were NOT tuned on.
-    Every line carries TWO fractions of the same K launches' worth of work: `frac_cold` — K launches right after the
-    W warm-up launches, the headline's own rule — and `frac` — K launches after a further SETTLE_S of untimed launches
-    (`untimed_settling_ms`), the steady state a long stream sees."""
+    Every line carries TWO fractions of the same K launches' worth of work: `frac` — K launches right after the
+    W warm-up launches, the headline's own rule (`value` and `ms_per_step` are these launches') — and `frac_settled` — K
+    launches after a further SETTLE_S of untimed launches (`untimed_settling_ms`), the steady state a long stream sees."""
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     import calendar
@@ -173,14 +174,14 @@ def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True, w
 
     for _ in range(warmup):
         plan.run(x.data_ptr(), it, out.data_ptr(), ot, stream.cuda_stream)
-    _, kms_cold = timed()                      # the headline's rule: W warm-up launches, then K timed ones
+    elapsed, kms_cold = timed()                # the headline's rule: W warm-up launches, then K timed ones -> value, frac
     t_s = time.perf_counter()
     while time.perf_counter() - t_s < SETTLE_S:
         for _ in range(10):
             plan.run(x.data_ptr(), it, out.data_ptr(), ot, stream.cuda_stream)
         torch.cuda.synchronize(dev)
     settle_ms = (time.perf_counter() - t_s) * 1e3
-    elapsed, kms = timed()
+    _, kms = timed()
     if DIST_ON:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -191,13 +192,13 @@ def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True, w
         frac = lambda ms: round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         prof = profiled(which) if world == 1 else None
         by_tiles = it != ot and layout.get("f32_i16_by_tiles")            # the mixed pairs of a many-matrix plan run on the tile kernel
-        roof = {"bound": "hbm", "achieved": round(alg / (kms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": frac(kms), "frac_cold": frac(kms_cold),
-                "frac_is": "K launches after %d ms of untimed launches (settled clocks); frac_cold: K launches right after the W warm-up "
-                           "launches, the headline's rule" % round(settle_ms),
+        roof = {"bound": "hbm", "achieved": round(alg / (kms_cold * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": frac(kms_cold), "frac_settled": frac(kms), "achieved_settled": round(alg / (kms * 1e-3) / 1e9, 1),
+                "frac_is": "K launches right after the W warm-up launches — the headline's rule (rounds 1-4's `frac`, round 5's `frac_cold`); "
+                           "frac_settled: K launches after a further %d ms of untimed launches (round 5's `frac`)" % round(settle_ms),
                 "traffic": prof["hbm_bytes_per_launch"] if prof and "hbm_bytes_per_launch" in prof else None,
                 "kernel": "dpx::span_kernel" if layout["walk_launches"] and not by_tiles else "dpx::tile_kernel", "layout": layout,
-                "avg_launch_ms": round(kms, 4), "avg_launch_ms_cold": round(kms_cold, 4), "algorithmic_bytes_per_launch": alg}
+                "avg_launch_ms": round(kms_cold, 4), "avg_launch_ms_settled": round(kms, 4), "algorithmic_bytes_per_launch": alg}
         if prof and prof.get("avg_launch_us_kernel_trace"):
             # from the committed rocprofv3 kernel trace of this workload (same kernel sources): ALL its launches, and the ones
             # that start more than 160 ms after the first
@@ -219,6 +220,135 @@ def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True, w
     plan.close()
     del x, out
     return line
+
+
+RING_SLAB_BYTES = 32 << 20      # the product ring's configuration in the driver's line: 4 slabs of 32 MiB (profiles/r06_ring.md)
+RING_SLABS = 4
+RING_GIB = 8                    # input through the ring per measurement (>= 4 GiB: VERDICT r05 item 1)
+
+
+def link_duplex(dev, nbytes, reps):
+    """What the PCIe link gives two free-running copy streams of pinned memory — H2D on one stream against D2H on another,
+    `reps` transfers of `nbytes` each, no ring, no dependencies: GB/s per direction (events on each stream)."""
+    h_up, h_dn = torch.empty(nbytes, dtype=torch.uint8).pin_memory(), torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    d_up, d_dn = torch.empty(nbytes, dtype=torch.uint8, device=dev), torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    s_up, s_dn = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    out = {}
+    for both in (False, True):
+        for _ in range(2):                       # first pass untimed
+            torch.cuda.synchronize(dev)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record(s_up)
+            ev[2].record(s_dn)
+            for _ in range(reps):
+                with torch.cuda.stream(s_up):
+                    d_up.copy_(h_up, non_blocking=True)
+                if both:
+                    with torch.cuda.stream(s_dn):
+                        h_dn.copy_(d_dn, non_blocking=True)
+            ev[1].record(s_up)
+            ev[3].record(s_dn)
+            torch.cuda.synchronize(dev)
+        if both:
+            out["h2d_GB_per_s_duplex"] = round(nbytes * reps / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9, 2)
+            out["d2h_GB_per_s_duplex"] = round(nbytes * reps / (ev[2].elapsed_time(ev[3]) * 1e-3) / 1e9, 2)
+        else:
+            out["h2d_GB_per_s_alone"] = round(nbytes * reps / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9, 2)
+    torch.cuda.synchronize(dev)
+    for _ in range(2):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            with torch.cuda.stream(s_dn):
+                h_dn.copy_(d_dn, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        out["d2h_GB_per_s_alone"] = round(nbytes * reps / (time.perf_counter() - t0) / 1e9, 2)
+    return out
+
+
+def drive_ring(ctxs, slab_bytes, n_slabs, total_bytes, fill, check=None, **stream_kw):
+    """The C-ABI slab ring (dpx_stream_create ... _release) driven from pinned memory as a producer with data at hand
+    would: every slab filled once by fill(j), one untimed lap (plans, device images, first touch of the output slabs;
+    check(j, view) sees its outputs), then next -> release -> acquire -> submit until total_bytes of input have gone
+    through.  Returns (seconds from the first timed submit to the last output handed back, bytes, describe(), stats)."""
+    import doppler_amd
+    ctxs = ctxs if isinstance(ctxs, (list, tuple)) else [ctxs]
+    st = doppler_amd.Stream(list(ctxs), "i16", "i16", RATE, slab_bytes=slab_bytes, n_slabs=n_slabs, **stream_kw)
+    try:
+        ring = n_slabs * len(ctxs)
+        segs = [(slab_bytes // 4, float(SHIFT))]
+        for j in range(ring):
+            fill(j, st.acquire())
+        for _ in range(ring):
+            st.submit(slab_bytes, segs)
+        for j in range(ring):
+            v = st.next_view()
+            if check is not None:
+                check(j, v)
+            st.release()
+        laps = max(ring, total_bytes // slab_bytes)
+        for _ in range(ring):
+            st.acquire()
+        t0 = time.perf_counter()
+        for _ in range(ring):
+            st.submit(slab_bytes, segs)
+        done, submitted = 0, ring
+        while done < laps:
+            st.next_view()
+            st.release()
+            done += 1
+            if submitted < laps:
+                st.acquire()
+                st.submit(slab_bytes, segs)
+                submitted += 1
+        dt = time.perf_counter() - t0
+        return dt, laps * slab_bytes, st.describe(), st.stats()
+    finally:
+        st.close()
+
+
+def stream_ring(ctx, dev, x, out):
+    """extra.stream_ring: the product's streaming path (dpx_stream_*: what `doppler const < in > out` runs on, reference
+    src/main.rs:57-99 with the blocks gathered into slabs) on ITS roofline, the PCIe link: headline shift, i16 -> i16, slabs
+    in pinned host memory, RING_GIB GiB of input through the ring.  `peak` = the slower direction of two free-running copy
+    streams (H2D against D2H, same transfer size, no ring) measured in the same run; the same ring without arithmetic
+    (DPX_STREAM_COPY_ONLY) is reported beside it.  x / out: the headline's device input and output (out is compared with the
+    oracle in the cpu_baseline leg of this run): the ring's first lap must reproduce out's first slabs byte for byte."""
+    import numpy as np
+    ring = RING_SLABS
+    xh = x[: ring * RING_SLAB_BYTES // 2].cpu().numpy().view(np.uint8)
+    oh = out[: ring * RING_SLAB_BYTES // 2].cpu().numpy().view(np.uint8)
+    same = []
+
+    def fill(j, buf):
+        buf[:] = xh[j * RING_SLAB_BYTES:(j + 1) * RING_SLAB_BYTES]
+
+    def check(j, v):
+        same.append(bool(np.array_equal(v, oh[j * RING_SLAB_BYTES:(j + 1) * RING_SLAB_BYTES])))
+
+    total = RING_GIB << 30
+    dt, nb, desc, stats = drive_ring(ctx, RING_SLAB_BYTES, ring, total, fill, check)
+    dt_copy, nb_copy, desc_copy, _ = drive_ring(ctx, RING_SLAB_BYTES, ring, total, fill, None, path=desc["path"], copy_only=True)
+    link = link_duplex(dev, RING_SLAB_BYTES, 64)
+    peak = min(link["h2d_GB_per_s_duplex"], link["d2h_GB_per_s_duplex"])
+    ach = nb / dt / 1e9
+    res = {
+        "what": "dpx_stream_* ring from pinned host memory: %d slabs of %d MiB, %d GiB of i16 IQ in and as much out, headline shift; "
+                "wall time from the first timed submit to the last output handed back (one untimed lap before)" %
+                (ring, RING_SLAB_BYTES >> 20, RING_GIB),
+        "Msamples_per_s": round(nb / 4 / dt / 1e6, 1), "seconds": round(dt, 4), "path": desc["path"],
+        "slab_bytes": RING_SLAB_BYTES, "slabs_in_flight": ring,
+        "first_lap_equals_the_device_resident_output": bool(same) and all(same),
+        "submit_us_per_slab": round(stats["total_us"] / max(1, stats["slabs"]), 2), "plans_reused": stats["plans_reused"],
+        "roofline": {"bound": "pcie", "unit": "GB/s per direction", "achieved": round(ach, 2), "peak": peak,
+                     "frac": round(ach / peak, 4),
+                     "peak_is": "the slower direction of H2D against D2H on two free-running streams of pinned memory, %d MiB transfers, "
+                                "no ring and no dependencies, same run" % (RING_SLAB_BYTES >> 20),
+                     "link": link,
+                     "copy_only_ring_GB_per_s": round(nb_copy / dt_copy / 1e9, 2),
+                     "frac_of_copy_only_ring": round(ach / (nb_copy / dt_copy / 1e9), 4),
+                     "algorithmic_bytes_per_sample_per_direction": 4},
+    }
+    return res
 
 
 def device_identity(dev_index):
@@ -255,8 +385,11 @@ def per_rank_report(rank, dev_index, avg_kernel_ms, elapsed_s):
 
 
 GATHER_TIMEOUT_S = 240
-PMC_PROFILE = "r05_pmc_traffic.json"     # tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes + a kernel-trace pass
-KERNEL_SOURCES = ["doppler_amd/csrc/dpx_kernels.hip", "doppler_amd/csrc/dpx_sincos.h", "doppler_amd/csrc/dpx_types.h"]
+PMC_PROFILE = "r06_pmc_traffic.json"     # tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes + a kernel-trace pass
+# everything that decides what a launch IS: the device code, and the host code that picks row lengths, spans, sub-launches and routing
+KERNEL_SOURCES = ["doppler_amd/csrc/dpx_kernels.hip", "doppler_amd/csrc/dpx_sincos.h", "doppler_amd/csrc/dpx_types.h",
+                  "doppler_amd/csrc/dpx_planner.cpp", "doppler_amd/csrc/dpx_planner.h", "doppler_amd/csrc/dpx_context.cpp",
+                  "doppler_amd/csrc/dpx_plans.cpp"]
 
 
 def kernel_source_sha():
@@ -282,7 +415,7 @@ def profiled(workload):
     return pj.get(workload)
 
 
-def build_result(args, world, n, elapsed, avg_kernel_ms, gather, plan_ms=None, one_shot_ms=None, per_rank=None):
+def build_result(args, world, n, elapsed, avg_kernel_ms, gather, plan_ms=None, one_shot_ms=None, per_rank=None, sustained=None):
     """The one JSON line of the headline workload (rank 0)."""
     achieved = n * BYTES_PER_SAMPLE / (avg_kernel_ms * 1e-3) / 1e9
     prof = profiled("const")
@@ -297,6 +430,11 @@ def build_result(args, world, n, elapsed, avg_kernel_ms, gather, plan_ms=None, o
         "traffic_source": ("profiles/%s (same kernel sources: sha %s)" % (PMC_PROFILE, kernel_source_sha())) if prof else
                           "none: no PMC profile of these kernel sources is committed (sha %s)" % kernel_source_sha(),
     }
+    if sustained:
+        roof["frac_sustained"] = sustained["frac"]
+        roof["sustained_s"] = sustained["sustained_s"]
+        roof["sustained_launches"] = sustained["launches"]
+        roof["avg_launch_ms_sustained"] = sustained["avg_launch_ms"]
     if prof and prof.get("avg_launch_us_kernel_trace"):
         us = prof["avg_launch_us_kernel_trace"]          # ALL launches of the committed kernel trace, warm-up included
         roof["frac_rocprof"] = round(n * BYTES_PER_SAMPLE / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
@@ -347,6 +485,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-sustain", action="store_true", help="skip the sustained leg (roofline.frac_sustained)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (replay) workloads appended under `extra`")
     ap.add_argument("--workload", default="const", choices=["const"] + sorted(REPLAYS),
                     help="const = the headline (default); track / track_256k / config4_chunk = secondary replay workloads")
@@ -446,6 +585,24 @@ def main():
     avg_kernel_ms = ev0.elapsed_time(ev1) / args.steps      # launch duration incl. the inter-launch gap
     per_rank = per_rank_report(rank, dev_index, avg_kernel_ms, LEGS["timed"])
 
+    # ---- outside the timed region: SUSTAIN_S seconds of back-to-back headline launches under one event pair — the settled
+    # figure of the headline (the secondary workloads carry theirs as frac_settled), and long enough for an outside sampler
+    # (the driver's gpu_busy, 5 s period) to see the GPU at work.  `value` / `ms_per_step` stay the K timed launches above.
+    sustained = None
+    if not args.no_sustain:
+        t_leg = time.perf_counter()
+        n_sus = max(args.steps, int(SUSTAIN_S / (avg_kernel_ms * 1e-3)) + 1)
+        es0, es1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        es0.record(stream)
+        for _ in range(n_sus):
+            step()
+        es1.record(stream)
+        torch.cuda.synchronize(dev)
+        sus_ms = es0.elapsed_time(es1)
+        sustained = {"launches": n_sus, "sustained_s": round(sus_ms * 1e-3, 3), "avg_launch_ms": round(sus_ms / n_sus, 4),
+                     "frac": round(n * BYTES_PER_SAMPLE / (sus_ms / n_sus * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        LEGS["sustained"] = round(time.perf_counter() - t_leg, 3)
+
     # ---- outside the timed region: ordered gather (multi-GPU), host round trip, CPU baseline
     gather = None
     t_leg = time.perf_counter()
@@ -465,7 +622,7 @@ def main():
             os._exit(0)
 
         def result_line(g):
-            return build_result(args, world, n, elapsed, avg_kernel_ms, g, round(plan_ms, 3), round(one_shot_ms, 3), per_rank)
+            return build_result(args, world, n, elapsed, avg_kernel_ms, g, round(plan_ms, 3), round(one_shot_ms, 3), per_rank, sustained)
 
         timer = threading.Timer(GATHER_TIMEOUT_S, give_up)
         timer.daemon = True
@@ -525,7 +682,7 @@ def main():
 
     result = None
     if rank == 0:
-        result = build_result(args, world, n, elapsed, avg_kernel_ms, gather, round(plan_ms, 3), round(one_shot_ms, 3), per_rank)
+        result = build_result(args, world, n, elapsed, avg_kernel_ms, gather, round(plan_ms, 3), round(one_shot_ms, 3), per_rank, sustained)
         if world == 1:
             # PCIe-inclusive figure (never `value`): pinned host -> HBM -> kernel -> pinned host
             t_leg = time.perf_counter()
@@ -546,6 +703,14 @@ def main():
             except Exception as e:  # pinning 2 GiB can fail on small hosts; the headline does not depend on it
                 result["host_round_trip"] = {"error": str(e)[:200]}
             LEGS["host_round_trip"] = round(time.perf_counter() - t_leg, 3)     # pinning 2 x 1 GiB is most of it
+            stream_ring_res = None
+            if not args.no_extra:
+                t_leg = time.perf_counter()
+                try:
+                    stream_ring_res = stream_ring(ctx, dev, x, out)
+                except Exception as e:
+                    stream_ring_res = {"error": str(e)[:300]}
+                LEGS["stream_ring"] = round(time.perf_counter() - t_leg, 3)
             if not args.no_cpu:
                 t_leg = time.perf_counter()
                 m = min(CPU_SAMPLE, n)
@@ -559,7 +724,7 @@ def main():
             if not args.no_extra:
                 # secondary workloads, after the timed region: they ride along in the driver's record.  BASELINE.json
                 # configs[2], the reference README's 256 ksps recording recipe, one GPU's chunk of configs[4].
-                result["extra"] = {}
+                result["extra"] = {"stream_ring": stream_ring_res}
                 for which in ("track", "track_256k", "config4_chunk"):
                     try:
                         result["extra"][which] = run_track(args, 1, 0, dev, ctx, steps=min(args.steps, 20),

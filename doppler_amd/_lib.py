@@ -42,6 +42,15 @@ class StreamStats(C.Structure):
                 ("enqueue_us", C.c_double), ("total_us", C.c_double)]
 
 
+class StreamOptions(C.Structure):
+    _fields_ = [("path", C.c_uint32), ("in_host_flags", C.c_uint32), ("out_host_flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+STREAM_PATHS = {"default": 0, "direct": 1, "staged": 2, "direct_in": 3, "direct_out": 4, "staged_per_slab": 5}
+STREAM_COPY_ONLY = 0x100
+STREAM_UNPACED = 0x200
+
+
 class ResidentCounters(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("blocks", C.c_uint64), ("stops", C.c_uint64), ("idle_exits", C.c_uint64),
                 ("running", C.c_uint32), ("tickets_in_flight", C.c_uint32), ("slots_parked", C.c_uint32), ("reserved", C.c_uint32)]
@@ -114,6 +123,8 @@ _SIGNATURES = {
     "dpx_plan_destroy": (None, [_vp]),
     "dpx_stream_create": (_i, [_vp, _i, _i, _u32, _u32, _sz, _i, _P(_vp)]),
     "dpx_stream_create_multi": (_i, [_P(_vp), _i, _i, _i, _u32, _u32, _sz, _i, _P(_vp)]),
+    "dpx_stream_create_opts": (_i, [_P(_vp), _i, _i, _i, _u32, _u32, _sz, _i, _vp, _P(_vp)]),
+    "dpx_stream_describe": (_i, [_vp, _P(_u32), _P(_i), _sz, _P(_sz)]),
     "dpx_stream_acquire": (_i, [_vp, _P(_vp), _P(_sz)]),
     "dpx_stream_submit": (_i, [_vp, _sz, _P(Segment), _sz]),
     "dpx_stream_pending": (_i, [_vp, _P(_i)]),

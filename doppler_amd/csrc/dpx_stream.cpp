@@ -1,6 +1,7 @@
 // dpx_stream.cpp — the slab ring: streaming from host memory, on one GPU or several
 // (one of the translation units behind include/doppler_hip*.h: see dpx_internal.h)
 #include <stdio.h>
+#include <stdlib.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -60,9 +61,11 @@ struct dpx_stream_slab {
     uint32_t key_sn_after = 0;
     dpx_ctx *ctx = nullptr;      // the GPU this slab is processed on (slab k of the ring belongs to context k mod n)
     char *h_in = nullptr, *h_out = nullptr;
-    void *d_in = nullptr, *d_out = nullptr;
-    hipStream_t stream = nullptr;
+    void *m_in = nullptr, *m_out = nullptr;   // the pinned buffers as the GPU addresses them (hipHostGetDevicePointer): the direct path's kernel arguments
+    void *d_in = nullptr, *d_out = nullptr;   // HBM staging of the copy-engine path (allocated only for the sides that are staged)
+    hipStream_t stream = nullptr;             // the slab's launches (and, on the per-slab form of the staged path, its copies)
     hipEvent_t done = nullptr;
+    hipEvent_t ev_up = nullptr, ev_run = nullptr;   // input has arrived in HBM / the launches are done: what links the three streams a staged slab crosses
     int numa_node = -1;          // where the pinned buffers were placed (-1: the caller's default policy)
     // several GPUs: the device work of a slab is enqueued by its GPU's own thread (dpx_stream::Worker)
     std::atomic<int> enq{0};     // 0: nothing pending; 1: handed to the worker; 2: enqueued (enq_rc says how it went)
@@ -86,6 +89,33 @@ struct dpx_stream {
     int in_fmt = 0, out_fmt = 0;
     uint32_t samplerate = 0, samplenum = 0;
     size_t slab_bytes = 0, slab_out = 0;
+    // How a slab crosses PCIe (dpx_stream_options.path).  DIRECT: the fused kernel loads from the pinned input slab and stores
+    // to the pinned output slab themselves — the samples cross the link once each way and never rest in HBM, reads and writes
+    // of ONE launch keep both directions of the link busy.  STAGED: copy engine H2D -> kernel HBM to HBM -> copy engine D2H on
+    // the slab's stream (rounds 2-5).  The two mixed forms stage one side only.  profiles/r06_ring.md has the same-process A/B.
+    uint32_t path = DPX_STREAM_PATH_DIRECT;
+    bool copy_only = false;      // calibration: the same slabs, the same path, no arithmetic (what the link gives the ring)
+    bool in_direct() const { return path == DPX_STREAM_PATH_DIRECT || path == DPX_STREAM_PATH_DIRECT_IN; }
+    bool out_direct() const { return path == DPX_STREAM_PATH_DIRECT || path == DPX_STREAM_PATH_DIRECT_OUT; }
+    bool per_slab() const { return path == DPX_STREAM_PATH_STAGED_PER_SLAB; }
+    // One stream per direction and GPU for the copy engines: every H2D of a GPU's slabs queues on `up`, every D2H on `down`,
+    // the launches stay on the slabs' own streams, events in between.  Measured (tools/pcie_probe.hip, profiles/r06_ring.md):
+    // ONE H2D stream against ONE D2H stream moves 56 + 48 GB/s; H2D -> kernel -> D2H on a stream per slab (rounds 2-5) takes
+    // turns at the link (28 GB/s each way: 1 / (1/57 + 1/51)) however many slabs are in flight.
+    // The D2H copies are PACED: a slab's copy is handed to the runtime only when the previous one of its GPU has finished.
+    // The runtime picks the copy engine of a D2H when it is submitted — the lowest engine that is idle at that moment
+    // (AMD_LOG_LEVEL=4: H2D always engine 0, D2H engines 1, 2, 3, ... as earlier ones still wait for their kernels) — and
+    // several engines copying D2H at once share the link badly: a ring of 4 (6) slabs whose D2H were all queued up front
+    // moved 27 (18-22) GB/s each way, the same ring paced 46-48.  dpx_stream_submit and dpx_stream_next both pump the queue;
+    // next(k) always can (the slab before k on its GPU has been handed out, so its copy is done).
+    struct Lane {
+        hipStream_t up = nullptr, down = nullptr;
+        std::mutex mu;                     // guards down_q / last_down (producer and consumer threads both pump)
+        std::deque<size_t> down_q;         // slabs whose launches are enqueued and whose D2H is not yet
+        long last_down = -1;               // slab of the newest D2H handed to the runtime
+    };
+    std::vector<std::unique_ptr<Lane>> lanes;     // one per context
+    bool paced = true;                     // dpx_stream_options.path | DPX_STREAM_UNPACED: every D2H queued at submit time (A/B)
     std::vector<dpx_stream_slab> slabs;
     size_t acq = 0;     // next slab to acquire            (producer side: acquire, then submit in the same order)
     size_t head = 0;    // oldest acquired slab, the next to submit
@@ -110,7 +140,9 @@ struct dpx_stream {
 };
 
 namespace {
+constexpr size_t kDirectBelow = 1u << 20, kStagedFrom = 4u << 20;     // slab sizes at which the default path changes (dpx_stream_create_opts)
 void slab_worker(dpx_stream *s, dpx_stream::Worker *w, int numa_node);
+int pump_down(dpx_stream *s, dpx_stream::Lane &lane, long upto);
 }
 
 namespace {
@@ -155,12 +187,18 @@ void prefer_numa_node(int node)
 
 extern "C" {
 
-int dpx_stream_create_multi(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_fmt, uint32_t samplerate,
-                            uint32_t samplenum0, size_t slab_bytes, int slabs_per_ctx, dpx_stream **out)
+int dpx_stream_create_opts(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_fmt, uint32_t samplerate,
+                           uint32_t samplenum0, size_t slab_bytes, int slabs_per_ctx, const dpx_stream_options *opt,
+                           dpx_stream **out)
 {
     if (!ctxs || n_ctx < 1 || n_ctx > 64 || !out || !fmt_ok(in_fmt) || !fmt_ok(out_fmt) || slabs_per_ctx < 1 ||
         (long)slabs_per_ctx * n_ctx > 256)
         return fail(DPX_ERR_ARG, "bad argument");
+    dpx_stream_options o = {};
+    if (opt) o = *opt;
+    else if (const char *e = getenv("DPX_STREAM_PATH")) o.path = (uint32_t)atoi(e);      // A/B of the shipped command without a rebuild
+    if ((o.path & 0xffu) > DPX_STREAM_PATH_STAGED_PER_SLAB || (o.path & ~(0xffu | DPX_STREAM_COPY_ONLY | DPX_STREAM_UNPACED)))
+        return fail(DPX_ERR_ARG, "unknown stream path %u", o.path);
     for (int i = 0; i < n_ctx; ++i)
         if (!ctxs[i]) return fail(DPX_ERR_ARG, "context %d is null", i);
     *out = nullptr;
@@ -177,7 +215,18 @@ int dpx_stream_create_multi(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out
     s->samplenum = samplenum0;
     s->slab_bytes = slab_bytes;
     s->slab_out = slab_bytes / ibs * obs;
+    // The default follows the slab size (same-process A/B on two boxes, i16 -> i16, GB/s of input; profiles/r06_ring.md):
+    //   slab       8 KiB  64 KiB  256 KiB  2 MiB  4 MiB  8 MiB  16 MiB  64 MiB
+    //   DIRECT      0.8    6.6     22.2    29.6   30.5   32.3   36.6    41.9     one launch, no copy engine: latency wins
+    //   DIRECT_OUT  0.5    3.2     11.1    33.6   39.0   38.9   41.4    44.0     engine H2D against the kernel's own stores
+    //   STAGED      0.3    2.3      7.9    33.2   38.7   43.1   45.8    47.2     engine H2D against engine D2H, paced
+    s->path = (o.path & 0xffu) != DPX_STREAM_PATH_DEFAULT ? (o.path & 0xffu)
+              : slab_bytes < kDirectBelow ? (uint32_t)DPX_STREAM_PATH_DIRECT
+              : slab_bytes < kStagedFrom ? (uint32_t)DPX_STREAM_PATH_DIRECT_OUT : (uint32_t)DPX_STREAM_PATH_STAGED;
+    s->copy_only = (o.path & DPX_STREAM_COPY_ONLY) != 0;
     s->slabs.resize((size_t)slabs_per_ctx * (size_t)n_ctx);
+    for (int i = 0; i < n_ctx; ++i) s->lanes.emplace_back(new dpx_stream::Lane);
+    s->paced = (o.path & DPX_STREAM_UNPACED) == 0;
     for (size_t k = 0; k < s->slabs.size(); ++k) {
         dpx_stream_slab &b = s->slabs[k];
         b.ctx = ctxs[k % (size_t)n_ctx];                 // consecutive slabs on consecutive GPUs: their copies and kernels overlap
@@ -188,16 +237,26 @@ int dpx_stream_create_multi(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out
         b.numa_node = node;
         if (node >= 0) prefer_numa_node(node);
         // portable: pinned for every device of the process, so that any slab can be handed to any GPU's DMA engines
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_in), slab_bytes, hipHostMallocPortable);
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_out), s->slab_out + 16, hipHostMallocPortable);
+        // (mapped: the direct path's kernels address them; extra flags — hipHostMallocNonCoherent, WriteCombined, NumaUser —
+        // only through dpx_stream_options, for the A/B of profiles/r06_ring.md)
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_in), slab_bytes, hipHostMallocPortable | hipHostMallocMapped | o.in_host_flags);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b.h_out), s->slab_out + 16, hipHostMallocPortable | hipHostMallocMapped | o.out_host_flags);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&b.m_in, b.h_in, 0);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&b.m_out, b.h_out, 0);
         if (node >= 0) {
             if (e == hipSuccess) { memset(b.h_in, 0, slab_bytes); memset(b.h_out, 0, s->slab_out + 16); }   // first touch under the policy, in case pinning left any page untouched
             prefer_numa_node(-1);
         }
-        if (e == hipSuccess) e = hipMalloc(&b.d_in, slab_bytes);
-        if (e == hipSuccess) e = hipMalloc(&b.d_out, s->slab_out + 16);
+        if (e == hipSuccess && !s->in_direct()) e = hipMalloc(&b.d_in, slab_bytes);
+        if (e == hipSuccess && !s->out_direct()) e = hipMalloc(&b.d_out, s->slab_out + 16);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b.ev_up, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b.ev_run, hipEventDisableTiming);
+        if (e == hipSuccess && k < (size_t)n_ctx) {       // the first slab of every context also makes its GPU's two copy streams
+            e = hipStreamCreateWithFlags(&s->lanes[k]->up, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->lanes[k]->down, hipStreamNonBlocking);
+        }
         if (e != hipSuccess) {
             dpx_stream_destroy(s);
             return fail(DPX_ERR_HIP, "stream slab allocation failed: %s", hipGetErrorString(e));
@@ -212,6 +271,12 @@ int dpx_stream_create_multi(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out
     }
     *out = s;
     return DPX_OK;
+}
+
+int dpx_stream_create_multi(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_fmt, uint32_t samplerate,
+                            uint32_t samplenum0, size_t slab_bytes, int slabs_per_ctx, dpx_stream **out)
+{
+    return dpx_stream_create_opts(ctxs, n_ctx, in_fmt, out_fmt, samplerate, samplenum0, slab_bytes, slabs_per_ctx, nullptr, out);
 }
 
 int dpx_stream_create(dpx_ctx *ctx, int in_fmt, int out_fmt, uint32_t samplerate, uint32_t samplenum0,
@@ -232,13 +297,21 @@ void dpx_stream_destroy(dpx_stream *s)
     for (dpx_stream_slab &b : s->slabs) {
         if (b.ctx) (void)hipSetDevice(b.ctx->device);
         if (b.stream) (void)hipStreamSynchronize(b.stream);
+        if (b.done) (void)hipEventSynchronize(b.done);      // (recorded on the GPU's `down` stream when the output is staged)
         if (b.h_in) (void)hipHostFree(b.h_in);
         if (b.h_out) (void)hipHostFree(b.h_out);
         if (b.d_in) (void)hipFree(b.d_in);
         if (b.d_out) (void)hipFree(b.d_out);
         release(b.dev);
         if (b.done) (void)hipEventDestroy(b.done);
+        if (b.ev_up) (void)hipEventDestroy(b.ev_up);
+        if (b.ev_run) (void)hipEventDestroy(b.ev_run);
         if (b.stream) (void)hipStreamDestroy(b.stream);
+    }
+    for (size_t i = 0; i < s->lanes.size(); ++i) {
+        (void)hipSetDevice(s->ctxs[i]->device);
+        if (s->lanes[i]->up) { (void)hipStreamSynchronize(s->lanes[i]->up); (void)hipStreamDestroy(s->lanes[i]->up); }
+        if (s->lanes[i]->down) { (void)hipStreamSynchronize(s->lanes[i]->down); (void)hipStreamDestroy(s->lanes[i]->down); }
     }
     delete s;
 }
@@ -259,6 +332,28 @@ int dpx_stream_acquire(dpx_stream *s, void **pinned_in, size_t *capacity_bytes)
 
 namespace {
 
+// Hands queued D2H copies of one GPU to the runtime, oldest first, each only once its predecessor has finished (`upto` >= 0:
+// everything up to and including that slab regardless — dpx_stream_next(k), which cannot wait for a copy nobody has issued).
+// The caller holds the device's lock and has made the device current.
+int pump_down(dpx_stream *s, dpx_stream::Lane &lane, long upto)
+{
+    std::lock_guard<std::mutex> lk(lane.mu);
+    while (!lane.down_q.empty()) {
+        const size_t k = lane.down_q.front();
+        bool forced = false;
+        if (upto >= 0)
+            for (size_t q : lane.down_q) forced = forced || q == (size_t)upto;
+        if (!forced && lane.last_down >= 0 && hipEventQuery(s->slabs[(size_t)lane.last_down].done) != hipSuccess) break;
+        dpx_stream_slab &b = s->slabs[k];
+        DPX_HIP(hipStreamWaitEvent(lane.down, b.ev_run, 0));
+        DPX_HIP(hipMemcpyAsync(b.h_out, b.d_out, b.out_bytes, hipMemcpyDeviceToHost, lane.down));
+        DPX_HIP(hipEventRecord(b.done, lane.down));
+        lane.last_down = (long)k;
+        lane.down_q.pop_front();
+    }
+    return DPX_OK;
+}
+
 // the device work of one submitted slab: plan image (unless the slab's resident one is reused), H2D, launch, D2H, event
 int enqueue_slab(dpx_stream *s, dpx_stream_slab &b, double *upload_us, double *enqueue_us)
 {
@@ -277,11 +372,41 @@ int enqueue_slab(dpx_stream *s, dpx_stream_slab &b, double *upload_us, double *e
     }
     const clk::time_point t2 = clk::now();
     *upload_us += us_since(t1);
-    DPX_HIP(hipMemcpyAsync(b.d_in, b.h_in, b.job_in_bytes, hipMemcpyHostToDevice, b.stream));
-    rc = run_plan(b.plan, b.dev, b.d_in, s->in_fmt, b.d_out, s->out_fmt, b.job_fma, b.job_geom, b.stream);
-    if (rc != DPX_OK) return rc;
-    DPX_HIP(hipMemcpyAsync(b.h_out, b.d_out, b.out_bytes, hipMemcpyDeviceToHost, b.stream));
-    DPX_HIP(hipEventRecord(b.done, b.stream));
+    const void *k_in = s->in_direct() ? b.m_in : b.d_in;
+    void *k_out = s->out_direct() ? b.m_out : b.d_out;
+    const size_t k_slab = (size_t)(&b - s->slabs.data());
+    dpx_stream::Lane &lane = *s->lanes[k_slab % s->lanes.size()];
+    hipStream_t st_up = s->per_slab() ? b.stream : lane.up, st_down = s->per_slab() ? b.stream : lane.down;
+    if (!s->in_direct()) {
+        DPX_HIP(hipMemcpyAsync(b.d_in, b.h_in, b.job_in_bytes, hipMemcpyHostToDevice, st_up));
+        if (st_up != b.stream) {
+            DPX_HIP(hipEventRecord(b.ev_up, st_up));
+            DPX_HIP(hipStreamWaitEvent(b.stream, b.ev_up, 0));
+        }
+    }
+    if (!s->copy_only) {
+        rc = run_plan(b.plan, b.dev, k_in, s->in_fmt, k_out, s->out_fmt, b.job_fma, b.job_geom, b.stream);
+        if (rc != DPX_OK) return rc;
+    } else if (s->in_direct() || s->out_direct()) {       // calibration: the kernel's side(s) of the link with no arithmetic
+        const size_t nb = (b.job_in_bytes < b.out_bytes ? b.job_in_bytes : b.out_bytes) & ~(size_t)15;
+        if (nb && dpx::launch_copy(k_in, k_out, nb, b.stream) != DPX_OK) return fail(DPX_ERR_HIP, "copy launch failed");
+    }
+    if (!s->out_direct()) {
+        if (st_down != b.stream) {
+            DPX_HIP(hipEventRecord(b.ev_run, b.stream));
+            {
+                std::lock_guard<std::mutex> lk(lane.mu);
+                lane.down_q.push_back(k_slab);
+            }
+            rc = pump_down(s, lane, s->paced ? -1 : (long)k_slab);
+            if (rc != DPX_OK) return rc;
+        } else {
+            DPX_HIP(hipMemcpyAsync(b.h_out, b.d_out, b.out_bytes, hipMemcpyDeviceToHost, st_down));
+            DPX_HIP(hipEventRecord(b.done, st_down));
+        }
+    } else {
+        DPX_HIP(hipEventRecord(b.done, b.stream));
+    }
     *enqueue_us += us_since(t2);
     return DPX_OK;
 }
@@ -436,7 +561,18 @@ int dpx_stream_next(dpx_stream *s, const void **pinned_out, size_t *out_bytes)
         }
         DPX_HIP(hipSetDevice(b.ctx->device));
     }
+    const bool staged_out = !s->out_direct() && !s->per_slab();
+    if (staged_out) {                      // the slab's D2H may still be queued behind its GPU's previous one (which is done: it was handed out)
+        DPX_ENTER(b.ctx);
+        const int rc = pump_down(s, *s->lanes[s->tail % s->lanes.size()], (long)s->tail);
+        if (rc != DPX_OK) return rc;
+    }
     DPX_HIP(hipEventSynchronize(b.done));
+    if (staged_out) {                      // ... and the next one of this GPU can go now
+        DPX_ENTER(b.ctx);
+        const int rc = pump_down(s, *s->lanes[s->tail % s->lanes.size()], -1);
+        if (rc != DPX_OK) return rc;
+    }
     b.state = 3;
     s->tail = (s->tail + 1) % s->slabs.size();
     *pinned_out = b.h_out;
@@ -460,6 +596,15 @@ int dpx_stream_get_stats(const dpx_stream *s, dpx_stream_stats *out)
     if (!s || !out) return fail(DPX_ERR_ARG, "bad argument");
     std::lock_guard<std::mutex> lk(s->enq_mu);          // the enqueue threads add their parts under this lock
     *out = s->stats;
+    return DPX_OK;
+}
+
+int dpx_stream_describe(const dpx_stream *s, uint32_t *path, int *numa_nodes, size_t cap, size_t *n_slabs)
+{
+    if (!s) return fail(DPX_ERR_ARG, "bad argument");
+    if (path) *path = s->path | (s->copy_only ? DPX_STREAM_COPY_ONLY : 0u) | (s->paced ? 0u : DPX_STREAM_UNPACED);
+    if (n_slabs) *n_slabs = s->slabs.size();
+    for (size_t k = 0; numa_nodes && k < cap && k < s->slabs.size(); ++k) numa_nodes[k] = s->slabs[k].numa_node;
     return DPX_OK;
 }
 

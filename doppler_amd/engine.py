@@ -187,17 +187,43 @@ class Stream:
     """Ring of pinned host slabs (dpx_stream_*): fill a slab, submit it with its constant-shift segments, collect
     the outputs in order.  The sample counter is carried from slab to slab like `samplenr` (main.rs:60)."""
 
-    def __init__(self, ctx, in_fmt, out_fmt, samplerate, samplenum=0, slab_bytes=8 << 20, n_slabs=3):
+    def __init__(self, ctx, in_fmt, out_fmt, samplerate, samplenum=0, slab_bytes=8 << 20, n_slabs=3, path=None,
+                 copy_only=False, in_host_flags=0, out_host_flags=0, unpaced=False):
         """ctx: one Context, or a list of Contexts (one per GPU; slab k runs on context k mod len(ctx), n_slabs slabs
-        per context)."""
+        per context).  path / copy_only / *_host_flags: dpx_stream_options (measurement only; None = the library's default)."""
         self._lib = _lib_handle()
         self.ctxs = list(ctx) if isinstance(ctx, (list, tuple)) else [ctx]
         self.ctx = self.ctxs[0]
         self.in_fmt, self.out_fmt = fmt_code(in_fmt), fmt_code(out_fmt)
         self._h = C.c_void_p()
         arr = (C.c_void_p * len(self.ctxs))(*[c.handle.value for c in self.ctxs])
-        check(self._lib.dpx_stream_create_multi(arr, len(self.ctxs), self.in_fmt, self.out_fmt, int(samplerate),
-                                                int(samplenum), int(slab_bytes), int(n_slabs), C.byref(self._h)))
+        if path is None and not copy_only and not in_host_flags and not out_host_flags and not unpaced:
+            check(self._lib.dpx_stream_create_multi(arr, len(self.ctxs), self.in_fmt, self.out_fmt, int(samplerate),
+                                                    int(samplenum), int(slab_bytes), int(n_slabs), C.byref(self._h)))
+        else:
+            opt = _lib.StreamOptions(_lib.STREAM_PATHS[path or "default"] | (_lib.STREAM_COPY_ONLY if copy_only else 0) | (_lib.STREAM_UNPACED if unpaced else 0),
+                                     int(in_host_flags), int(out_host_flags), 0)
+            check(self._lib.dpx_stream_create_opts(arr, len(self.ctxs), self.in_fmt, self.out_fmt, int(samplerate),
+                                                   int(samplenum), int(slab_bytes), int(n_slabs), C.byref(opt), C.byref(self._h)))
+
+    def describe(self):
+        """{'path': name, 'copy_only': bool, 'numa_nodes': [node of every slab's pinned buffers, -1 = the caller's policy]}"""
+        path, n = C.c_uint32(), C.c_size_t()
+        check(self._lib.dpx_stream_describe(self._h, C.byref(path), None, 0, C.byref(n)))
+        nodes = (C.c_int * max(1, n.value))()
+        check(self._lib.dpx_stream_describe(self._h, C.byref(path), nodes, n.value, C.byref(n)))
+        names = {v: k for k, v in _lib.STREAM_PATHS.items()}
+        return {"path": names[path.value & 0xff], "copy_only": bool(path.value & _lib.STREAM_COPY_ONLY),
+                "numa_nodes": list(nodes[: n.value])}
+
+    def next_view(self):
+        """Waits for the oldest submitted slab; returns a VIEW of its pinned output (valid until release())."""
+        p, nb = C.c_void_p(), C.c_size_t()
+        check(self._lib.dpx_stream_next(self._h, C.byref(p), C.byref(nb)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(nb.value, 1),))[: nb.value]
+
+    def release(self):
+        check(self._lib.dpx_stream_release(self._h))
 
     def acquire(self):
         """numpy uint8 view of the next free pinned input slab (raises DspError ERR_PLAN when all are in flight)."""

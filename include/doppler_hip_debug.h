@@ -117,6 +117,36 @@ typedef struct dpx_stream_stats {
 } dpx_stream_stats;
 int dpx_stream_get_stats(const dpx_stream *s, dpx_stream_stats *out);
 
+/* How the slabs of a ring cross PCIe — for the same-process A/B behind the default (profiles/r06_ring.md); never changes a byte.
+ *   DPX_STREAM_PATH_DIRECT      the fused kernel loads from the pinned input slab and stores to the pinned output slab
+ *                               (host-mapped memory): no HBM staging, no copy engine, one launch per slab   [the default]
+ *   DPX_STREAM_PATH_STAGED      copy engine H2D -> kernel HBM to HBM -> copy engine D2H on the slab's stream (rounds 2-5)
+ *   DPX_STREAM_PATH_DIRECT_IN   kernel loads from the host slab, output staged;  _DIRECT_OUT: input staged, kernel stores to host
+ *   | DPX_STREAM_COPY_ONLY      calibration: the same slabs on the same path without arithmetic (a plain copy kernel on the
+ *                               kernel's side of the link, nothing at all between the two engine copies of STAGED): the
+ *                               rate the link gives THIS ring — the `peak` of bench.py's extra.stream_ring
+ * in/out_host_flags: extra hipHostMalloc flags of the input / output slabs (hipHostMallocNonCoherent 0x80000000,
+ * hipHostMallocWriteCombined 0x4, hipHostMallocNumaUser 0x20000000).
+ * opt == NULL: the defaults (path from DPX_STREAM_PATH in the environment when set). */
+#define DPX_STREAM_PATH_DEFAULT 0u
+#define DPX_STREAM_PATH_DIRECT 1u
+#define DPX_STREAM_PATH_STAGED 2u
+#define DPX_STREAM_PATH_DIRECT_IN 3u
+#define DPX_STREAM_PATH_DIRECT_OUT 4u
+#define DPX_STREAM_PATH_STAGED_PER_SLAB 5u
+#define DPX_STREAM_COPY_ONLY 0x100u
+#define DPX_STREAM_UNPACED 0x200u
+typedef struct dpx_stream_options {
+    uint32_t path;
+    uint32_t in_host_flags, out_host_flags;
+    uint32_t reserved;
+} dpx_stream_options;
+int dpx_stream_create_opts(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_fmt, uint32_t samplerate,
+                           uint32_t samplenum0, size_t slab_bytes, int slabs_per_ctx, const dpx_stream_options *opt,
+                           dpx_stream **stream);
+/* the path a ring runs on (one of the four above) and the NUMA node each slab's pinned buffers were placed on (-1: the caller's policy) */
+int dpx_stream_describe(const dpx_stream *s, uint32_t *path, int *numa_nodes, size_t cap, size_t *n_slabs);
+
 /* Same access pattern, no arithmetic: 16-byte non-temporal copy of n_bytes.
  * Calibration only (profiles/: what the memory system gives a pure stream). */
 int dpx_debug_copy(dpx_ctx *ctx, const void *d_in, void *d_out, size_t n_bytes, void *hip_stream);

@@ -1,0 +1,131 @@
+"""The slab ring (dpx_stream_*, reference src/main.rs:57-99 gathered into slabs) on each of its PCIe paths against the
+oracle: DIRECT (the fused kernel loads from / stores to the pinned host slabs — the default), STAGED (copy engines either
+side of an HBM-to-HBM launch), and the two mixed forms.  Every comparison is exact equality of output bytes."""
+import numpy as np
+import pytest
+
+from helpers import BPS, assert_same_bytes, make_iq
+
+pytestmark = pytest.mark.gpu
+
+PATHS = ["direct", "staged", "direct_in", "direct_out", "staged_per_slab"]
+NONCOHERENT, NUMAUSER = 0x80000000, 0x20000000
+
+
+def drive(st, x, bi, slabs, n_ring):
+    """slabs: [(n_samples, segments)]; returns the concatenated output, feeding the ring to capacity."""
+    outs, pos = [], 0
+    for n, segs in slabs:
+        if st.pending() == n_ring:
+            outs.append(st.next())
+        buf = st.acquire()
+        buf[: n * bi] = x[pos * bi:(pos + n) * bi]
+        st.submit(n * bi, segs)
+        pos += n
+    while st.pending():
+        outs.append(st.next())
+    return np.concatenate(outs) if outs else np.empty(0, np.uint8)
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("intype,outtype,shift,rate", [("i16", "i16", 5000, 1024000), ("f32", "f32", -15000, 256000),
+                                                       ("i16", "f32", 5001, 1024000), ("f32", "i16", 3, 1024000)])
+def test_const_stream_through_the_ring(ctx, orc, path, intype, outtype, shift, rate):
+    """`doppler const`: slabs of full and ragged sizes, every slab buffer used several times with new content (a kernel that
+    reads host memory must never see a previous lap's bytes), counter carried — equal to the oracle's sequential pass over the whole stream."""
+    import doppler_amd
+    bi = BPS[intype]
+    slab_bytes, n_ring = 1 << 19, 3
+    per = slab_bytes // bi
+    sizes = [per, per, per - 8, per, 1, per, per // 2 + 3, per, per, 2048, per, per - 1]
+    n = sum(sizes)
+    x = make_iq(intype, n, 1234, full_scale=True)
+    st = doppler_amd.Stream(ctx, intype, outtype, rate, slab_bytes=slab_bytes, n_slabs=n_ring, path=path)
+    try:
+        assert st.describe()["path"] == path and not st.describe()["copy_only"]
+        got = drive(st, x, bi, [(m, [(m, float(shift))]) for m in sizes], n_ring)
+        want, sn = orc.segments_stream(x, intype, outtype, [(n, float(shift))], rate, threads=8)
+        assert st.samplenum == sn
+        assert_same_bytes(got, want, outtype, "ring path %s" % path)
+    finally:
+        st.close()
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_track_segments_through_the_ring(ctx, orc, path):
+    """`doppler track`: shift changes inside and between slabs (span and tile kernels reading / writing host memory)."""
+    import doppler_amd
+    rate = 1024000
+    rng = np.random.default_rng(5)
+    slab_bytes, n_ring = 1 << 20, 4
+    per = slab_bytes // 4
+    slabs, all_segs = [], []
+    for k in range(11):
+        m = per if k % 3 else int(rng.integers(1, per))
+        cuts = sorted(set(int(c) for c in rng.integers(1, m, size=3))) if m > 4 else []
+        bounds = [0] + cuts + [m]
+        segs = [(b - a, float(np.float32(4000.0 + 13.25 * k + i))) for i, (a, b) in enumerate(zip(bounds[:-1], bounds[1:]))]
+        slabs.append((m, segs))
+        all_segs += segs
+    n = sum(m for m, _ in slabs)
+    x = make_iq("i16", n, 77, full_scale=True)
+    st = doppler_amd.Stream(ctx, "i16", "i16", rate, slab_bytes=slab_bytes, n_slabs=n_ring, path=path)
+    try:
+        got = drive(st, x, 4, slabs, n_ring)
+        want, sn = orc.segments_stream(x, "i16", "i16", all_segs, rate, threads=8)
+        assert st.samplenum == sn
+        assert_same_bytes(got, want, "i16", "track ring path %s" % path)
+    finally:
+        st.close()
+
+
+def test_default_path_is_the_direct_one_and_the_environment_selects(ctx, orc, monkeypatch):
+    import doppler_amd
+    st = doppler_amd.Stream(ctx, "i16", "i16", 1024000, slab_bytes=1 << 16, n_slabs=2)
+    assert st.describe()["path"] == "direct"
+    st.close()
+    monkeypatch.setenv("DPX_STREAM_PATH", "2")
+    st = doppler_amd.Stream(ctx, "i16", "i16", 1024000, slab_bytes=1 << 16, n_slabs=2)
+    assert st.describe()["path"] == "staged"
+    st.close()
+    monkeypatch.setenv("DPX_STREAM_PATH", "9")
+    with pytest.raises(doppler_amd.DspError):
+        doppler_amd.Stream(ctx, "i16", "i16", 1024000, slab_bytes=1 << 16, n_slabs=2)
+
+
+@pytest.mark.parametrize("flags", [(NONCOHERENT, NONCOHERENT), (NONCOHERENT, 0), (0, NONCOHERENT), (NUMAUSER, NUMAUSER)])
+def test_direct_path_with_other_host_memory_kinds(ctx, orc, flags):
+    """The A/B's alternatives keep the bytes: non-coherent (GPU-cacheable) host slabs rewritten by the CPU between laps."""
+    import doppler_amd
+    rate, shift = 1024000, 5000
+    slab_bytes, n_ring = 1 << 18, 2
+    per = slab_bytes // 4
+    sizes = [per] * 9 + [per - 4]
+    x = make_iq("i16", sum(sizes), 4321)
+    st = doppler_amd.Stream(ctx, "i16", "i16", rate, slab_bytes=slab_bytes, n_slabs=n_ring, path="direct",
+                            in_host_flags=flags[0], out_host_flags=flags[1])
+    try:
+        got = drive(st, x, 4, [(m, [(m, float(shift))]) for m in sizes], n_ring)
+        want, sn = orc.segments_stream(x, "i16", "i16", [(sum(sizes), float(shift))], rate, threads=8)
+        assert st.samplenum == sn
+        assert_same_bytes(got, want, "i16", "direct ring, host flags %r" % (flags,))
+    finally:
+        st.close()
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_copy_only_calibration_moves_the_bytes_it_claims(ctx, path):
+    """DPX_STREAM_COPY_ONLY is the `peak` of bench.py's extra.stream_ring: on the paths with a kernel side the slab's bytes must
+    really cross (output == input for equal formats); the engine-only path moves both slabs' worth without relating them."""
+    import doppler_amd
+    slab_bytes = 1 << 18
+    x = make_iq("i16", 3 * slab_bytes // 4, 9)
+    st = doppler_amd.Stream(ctx, "i16", "i16", 1024000, slab_bytes=slab_bytes, n_slabs=2, path=path, copy_only=True)
+    try:
+        assert st.describe()["copy_only"]
+        got = drive(st, x, 4, [(slab_bytes // 4, [(slab_bytes // 4, 5000.0)])] * 3, 2)
+        assert got.size == x.size
+        if not path.startswith("staged"):
+            assert np.array_equal(got, x)
+    finally:
+        st.close()
