@@ -224,7 +224,11 @@ def run_track(args, world, rank, dev, ctx, steps=None, warmup=None, emit=True, w
 
 RING_SLAB_BYTES = 32 << 20      # the product ring's configuration in the driver's line: 4 slabs of 32 MiB (profiles/r06_ring.md)
 RING_SLABS = 4
-RING_GIB = 8                    # input through the ring per measurement (>= 4 GiB: VERDICT r05 item 1)
+RING_GIB = 16                   # input through the ring per measurement (>= 4 GiB: VERDICT r05 item 1)
+RING_WARM_S = 0.6               # untimed cycling before a ring measurement
+PRODUCT_RING_SLAB_BYTES = 64 << 20   # N > 1: the N-device ring rank 0 runs after the gather leg (gather.product_ring)
+PRODUCT_RING_SLABS = 3               # per GPU
+PRODUCT_RING_S = 2.0
 
 
 def link_duplex(dev, nbytes, reps):
@@ -265,11 +269,14 @@ def link_duplex(dev, nbytes, reps):
     return out
 
 
-def drive_ring(ctxs, slab_bytes, n_slabs, total_bytes, fill, check=None, **stream_kw):
+def drive_ring(ctxs, slab_bytes, n_slabs, total_bytes, fill, check=None, warm_s=RING_WARM_S, **stream_kw):
     """The C-ABI slab ring (dpx_stream_create ... _release) driven from pinned memory as a producer with data at hand
     would: every slab filled once by fill(j), one untimed lap (plans, device images, first touch of the output slabs;
-    check(j, view) sees its outputs), then next -> release -> acquire -> submit until total_bytes of input have gone
-    through.  Returns (seconds from the first timed submit to the last output handed back, bytes, describe(), stats)."""
+    check(j, view) sees its outputs), warm_s seconds of untimed cycling (a process's first 0.2-0.3 s of heavy PCIe traffic
+    hold one 30-50 ms stall, whatever the path: profiles/r06_ring.md), then next -> release -> acquire -> submit until
+    total_bytes of input have gone through.  Returns (seconds from the first timed submit to the last output handed back,
+    bytes, describe(), stats, GB/s of input in windows of 50 ms: (min, median))."""
+    import numpy as np
     import doppler_amd
     ctxs = ctxs if isinstance(ctxs, (list, tuple)) else [ctxs]
     st = doppler_amd.Stream(list(ctxs), "i16", "i16", RATE, slab_bytes=slab_bytes, n_slabs=n_slabs, **stream_kw)
@@ -285,25 +292,68 @@ def drive_ring(ctxs, slab_bytes, n_slabs, total_bytes, fill, check=None, **strea
             if check is not None:
                 check(j, v)
             st.release()
-        laps = max(ring, total_bytes // slab_bytes)
-        for _ in range(ring):
-            st.acquire()
-        t0 = time.perf_counter()
-        for _ in range(ring):
-            st.submit(slab_bytes, segs)
-        done, submitted = 0, ring
-        while done < laps:
-            st.next_view()
-            st.release()
-            done += 1
-            if submitted < laps:
+
+        def cycle(stop):
+            """keeps the ring full until stop(done) says so; returns the completion times of the slabs handed back"""
+            for _ in range(ring):
                 st.acquire()
+            t0 = time.perf_counter()
+            for _ in range(ring):
                 st.submit(slab_bytes, segs)
-                submitted += 1
-        dt = time.perf_counter() - t0
-        return dt, laps * slab_bytes, st.describe(), st.stats()
+            stamps, submitted = [], ring
+            while len(stamps) < submitted:
+                st.next_view()
+                st.release()
+                stamps.append(time.perf_counter() - t0)
+                if not stop(len(stamps), stamps[-1]) and submitted < (1 << 40):
+                    st.acquire()
+                    st.submit(slab_bytes, segs)
+                    submitted += 1
+            return stamps
+
+        if warm_s > 0:
+            cycle(lambda done, t: t >= warm_s)
+        laps = max(ring, total_bytes // slab_bytes)
+        stamps = cycle(lambda done, t: done + ring > laps)
+        dt = stamps[-1]
+        w = 0.05
+        cnt, _ = np.histogram(np.array(stamps), np.arange(0.0, dt, w)) if dt > 3 * w else (np.array([len(stamps)]), None)
+        rates = cnt * slab_bytes / (w if dt > 3 * w else dt) / 1e9
+        return dt, len(stamps) * slab_bytes, st.describe(), st.stats(), (round(float(rates.min()), 2), round(float(np.median(rates)), 2))
     finally:
         st.close()
+
+
+def product_ring(devices, seconds=PRODUCT_RING_S):
+    """gather.product_ring (N > 1): dpx_stream_create_multi over all N devices from ONE process, driven from pinned memory
+    for about `seconds`: aggregate rate, the rate per device, where every slab's pinned buffers live."""
+    import numpy as np
+    import doppler_amd
+    ctxs = [doppler_amd.Context(d) for d in devices]
+    try:
+        slab = PRODUCT_RING_SLAB_BYTES
+        pat = np.random.default_rng(3).integers(-23170, 23171, size=slab // 2, dtype=np.int16).view(np.uint8)
+
+        def fill(j, buf):
+            buf[:] = pat
+
+        # sized by time: about `seconds` at the single-GPU ring's rate per device
+        total = int(seconds * 45e9 * len(set(devices))) // slab * slab
+        dt, nb, desc, stats, win = drive_ring(ctxs, slab, PRODUCT_RING_SLABS, total, fill, None, warm_s=RING_WARM_S)
+        n = len(ctxs)
+        return {"what": "dpx_stream_create_multi over %d device(s) from one process (what `doppler --gpus N` runs on): %d slabs of %d MiB per "
+                        "GPU in pinned host memory, headline shift, i16 -> i16, slab k on GPU k mod N, per-GPU D2H, outputs in order" %
+                        (n, PRODUCT_RING_SLABS, slab >> 20),
+                "devices": devices, "Msamples_per_s": round(nb / 4 / dt / 1e6, 1), "seconds": round(dt, 3),
+                "GB_per_s_each_way_aggregate": round(nb / dt / 1e9, 2), "GB_per_s_each_way_per_device": round(nb / dt / 1e9 / n, 2),
+                "GB_per_s_in_50ms_windows": {"min": win[0], "median": win[1]},
+                "path": desc["path"], "stream_probe_rounds": desc.get("probe_rounds"), "streams_share_a_queue": desc.get("streams_share_a_queue"),
+                "slab_numa_nodes": desc["numa_nodes"], "submit_us_per_slab": round(stats["total_us"] / max(1, stats["slabs"]), 2),
+                "producer": "one Python thread: acquire / submit / next / release per slab (%.0f us of dpx_stream_submit per slab)" %
+                            (stats["total_us"] / max(1, stats["slabs"]))}
+    finally:
+        for c in ctxs:
+            c.close()
 
 
 def stream_ring(ctx, dev, x, out):
@@ -326,19 +376,21 @@ def stream_ring(ctx, dev, x, out):
         same.append(bool(np.array_equal(v, oh[j * RING_SLAB_BYTES:(j + 1) * RING_SLAB_BYTES])))
 
     total = RING_GIB << 30
-    dt, nb, desc, stats = drive_ring(ctx, RING_SLAB_BYTES, ring, total, fill, check)
-    dt_copy, nb_copy, desc_copy, _ = drive_ring(ctx, RING_SLAB_BYTES, ring, total, fill, None, path=desc["path"], copy_only=True)
+    dt, nb, desc, stats, win = drive_ring(ctx, RING_SLAB_BYTES, ring, total, fill, check)
+    dt_copy, nb_copy, desc_copy, _, _ = drive_ring(ctx, RING_SLAB_BYTES, ring, total, fill, None, path=desc["path"], copy_only=True)
     link = link_duplex(dev, RING_SLAB_BYTES, 64)
     peak = min(link["h2d_GB_per_s_duplex"], link["d2h_GB_per_s_duplex"])
     ach = nb / dt / 1e9
     res = {
         "what": "dpx_stream_* ring from pinned host memory: %d slabs of %d MiB, %d GiB of i16 IQ in and as much out, headline shift; "
-                "wall time from the first timed submit to the last output handed back (one untimed lap before)" %
-                (ring, RING_SLAB_BYTES >> 20, RING_GIB),
+                "wall time from the first timed submit to the last output handed back (one untimed lap and %.1f s of untimed cycling before)" %
+                (ring, RING_SLAB_BYTES >> 20, RING_GIB, RING_WARM_S),
         "Msamples_per_s": round(nb / 4 / dt / 1e6, 1), "seconds": round(dt, 4), "path": desc["path"],
-        "slab_bytes": RING_SLAB_BYTES, "slabs_in_flight": ring,
+        "slab_bytes": RING_SLAB_BYTES, "slabs_in_flight": ring, "stream_probe_rounds": desc.get("probe_rounds"),
+        "streams_share_a_queue": desc.get("streams_share_a_queue"),
         "first_lap_equals_the_device_resident_output": bool(same) and all(same),
         "submit_us_per_slab": round(stats["total_us"] / max(1, stats["slabs"]), 2), "plans_reused": stats["plans_reused"],
+        "GB_per_s_in_50ms_windows": {"min": win[0], "median": win[1]},
         "roofline": {"bound": "pcie", "unit": "GB/s per direction", "achieved": round(ach, 2), "peak": peak,
                      "frac": round(ach / peak, 4),
                      "peak_is": "the slower direction of H2D against D2H on two free-running streams of pinned memory, %d MiB transfers, "
@@ -676,6 +728,24 @@ def main():
             del ho
         except Exception as e:
             gather["per_gpu_d2h"] = {"error": str(e)[:300]}
+        # ---- what SHIPS for a host consumer (README.md's stated deviation): `doppler --gpus N` / dpx_stream_create_multi, ONE
+        # process feeding every GPU's slab ring from pinned memory, per-GPU D2H, outputs in order.  The other ranks free
+        # their buffers and wait at the barrier while rank 0 opens a context on every device and runs that ring.
+        if world > 1 or os.environ.get("DPX_BENCH_FORCE_PRODUCT_RING") == "1":
+            try:
+                if rank != 0:
+                    del x, out
+                    x = out = None
+                    torch.cuda.empty_cache()
+                barrier()
+                if rank == 0:
+                    devices = [0] * world if share else list(range(world))
+                    gather["product_ring"] = product_ring(devices)
+                barrier()
+            except Exception as e:
+                if gather is None:
+                    gather = {}
+                gather["product_ring"] = {"error": str(e)[:300]}
         gather_state["done"] = True
         timer.cancel()
         LEGS["gather"] = round(time.perf_counter() - t_leg, 3)

@@ -49,6 +49,8 @@ class StreamOptions(C.Structure):
 STREAM_PATHS = {"default": 0, "direct": 1, "staged": 2, "direct_in": 3, "direct_out": 4, "staged_per_slab": 5}
 STREAM_COPY_ONLY = 0x100
 STREAM_UNPACED = 0x200
+STREAM_NO_PROBE = 0x400
+STREAM_SHARED_QUEUE = 0x800
 
 
 class ResidentCounters(C.Structure):

@@ -5,6 +5,7 @@
 #include <sys/syscall.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -63,7 +64,9 @@ struct dpx_stream_slab {
     char *h_in = nullptr, *h_out = nullptr;
     void *m_in = nullptr, *m_out = nullptr;   // the pinned buffers as the GPU addresses them (hipHostGetDevicePointer): the direct path's kernel arguments
     void *d_in = nullptr, *d_out = nullptr;   // HBM staging of the copy-engine path (allocated only for the sides that are staged)
-    hipStream_t stream = nullptr;             // the slab's launches (and, on the per-slab form of the staged path, its copies)
+    hipStream_t stream = nullptr;             // the slab's launches: its own stream where the kernel itself crosses PCIe (launches of several slabs
+                                              // overlap) and on the per-slab form of the staged path; the GPU's `run` stream on the staged path
+    bool owns_stream = false;
     hipEvent_t done = nullptr;
     hipEvent_t ev_up = nullptr, ev_run = nullptr;   // input has arrived in HBM / the launches are done: what links the three streams a staged slab crosses
     int numa_node = -1;          // where the pinned buffers were placed (-1: the caller's default policy)
@@ -109,10 +112,14 @@ struct dpx_stream {
     // moved 27 (18-22) GB/s each way, the same ring paced 46-48.  dpx_stream_submit and dpx_stream_next both pump the queue;
     // next(k) always can (the slab before k on its GPU has been handed out, so its copy is done).
     struct Lane {
-        hipStream_t up = nullptr, down = nullptr;
+        hipStream_t up = nullptr, run = nullptr, down = nullptr;
         std::mutex mu;                     // guards down_q / last_down (producer and consumer threads both pump)
         std::deque<size_t> down_q;         // slabs whose launches are enqueued and whose D2H is not yet
         long last_down = -1;               // slab of the newest D2H handed to the runtime
+        std::vector<hipStream_t> parked;   // streams that shared a hardware queue with another of the three: kept (idle) so that
+                                           // their replacements are dealt a different queue, destroyed with the ring
+        int probes = 0;                    // rounds of separate_lane_streams (dpx_stream_describe: 0 = not probed)
+        bool shared_queue = false;         // ... and whether the last round still saw two of the streams wait for each other
     };
     std::vector<std::unique_ptr<Lane>> lanes;     // one per context
     bool paced = true;                     // dpx_stream_options.path | DPX_STREAM_UNPACED: every D2H queued at submit time (A/B)
@@ -143,6 +150,7 @@ namespace {
 constexpr size_t kDirectBelow = 1u << 20, kStagedFrom = 4u << 20;     // slab sizes at which the default path changes (dpx_stream_create_opts)
 void slab_worker(dpx_stream *s, dpx_stream::Worker *w, int numa_node);
 int pump_down(dpx_stream *s, dpx_stream::Lane &lane, long upto);
+void separate_lane_streams(dpx_stream *s, size_t lane_index);
 }
 
 namespace {
@@ -197,7 +205,7 @@ int dpx_stream_create_opts(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_
     dpx_stream_options o = {};
     if (opt) o = *opt;
     else if (const char *e = getenv("DPX_STREAM_PATH")) o.path = (uint32_t)atoi(e);      // A/B of the shipped command without a rebuild
-    if ((o.path & 0xffu) > DPX_STREAM_PATH_STAGED_PER_SLAB || (o.path & ~(0xffu | DPX_STREAM_COPY_ONLY | DPX_STREAM_UNPACED)))
+    if ((o.path & 0xffu) > DPX_STREAM_PATH_STAGED_PER_SLAB || (o.path & ~(0xffu | DPX_STREAM_COPY_ONLY | DPX_STREAM_UNPACED | DPX_STREAM_NO_PROBE)))
         return fail(DPX_ERR_ARG, "unknown stream path %u", o.path);
     for (int i = 0; i < n_ctx; ++i)
         if (!ctxs[i]) return fail(DPX_ERR_ARG, "context %d is null", i);
@@ -231,9 +239,10 @@ int dpx_stream_create_opts(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_
         dpx_stream_slab &b = s->slabs[k];
         b.ctx = ctxs[k % (size_t)n_ctx];                 // consecutive slabs on consecutive GPUs: their copies and kernels overlap
         hipError_t e = hipSetDevice(b.ctx->device);
-        // A slab's pinned buffers live on the NUMA node of ITS GPU (several GPUs only: one GPU's ring stays where its caller
-        // runs): the pages are taken while the buffer is pinned, under this thread's policy.
-        const int node = n_ctx > 1 ? gpu_numa_node(b.ctx->device) : -1;
+        // A slab's pinned buffers live on the NUMA node of ITS GPU: the pages are taken while the buffer is pinned, under this
+        // thread's policy.  One GPU too (round 6): a ring whose slabs landed on the other socket — wherever the creating thread
+        // happened to run — moved 26 GB/s each way instead of 47, one ring instance in ten on a two-socket box.
+        const int node = gpu_numa_node(b.ctx->device);
         b.numa_node = node;
         if (node >= 0) prefer_numa_node(node);
         // portable: pinned for every device of the process, so that any slab can be handed to any GPU's DMA engines
@@ -249,19 +258,32 @@ int dpx_stream_create_opts(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_
         }
         if (e == hipSuccess && !s->in_direct()) e = hipMalloc(&b.d_in, slab_bytes);
         if (e == hipSuccess && !s->out_direct()) e = hipMalloc(&b.d_out, s->slab_out + 16);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking);
+        if (e == hipSuccess && k < (size_t)n_ctx) {
+            // The first slab of every context makes its GPU's streams, one after the other: the runtime deals streams out
+            // over a handful of hardware queues (4 by default), and two ACTIVE streams on one hardware queue wait for each
+            // other's copies — `up` and `down` on one queue is H2D and D2H taking turns (28 GB/s each way; seen in a process
+            // that already held streams: bench.py with torch, GPU_MAX_HW_QUEUES=4 against 16).  Three streams created
+            // back to back land on different queues; a stream per slab on top of them (rounds 2-5, and this round's first
+            // form of the staged path) did not.
+            dpx_stream::Lane &ln = *s->lanes[k];
+            e = hipStreamCreateWithFlags(&ln.up, hipStreamNonBlocking);
+            if (e == hipSuccess && s->path == DPX_STREAM_PATH_STAGED) e = hipStreamCreateWithFlags(&ln.run, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&ln.down, hipStreamNonBlocking);
+        }
+        if (e == hipSuccess) {
+            if (s->path == DPX_STREAM_PATH_STAGED) b.stream = s->lanes[k % (size_t)n_ctx]->run;
+            else { e = hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking); b.owns_stream = e == hipSuccess; }
+        }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b.ev_up, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b.ev_run, hipEventDisableTiming);
-        if (e == hipSuccess && k < (size_t)n_ctx) {       // the first slab of every context also makes its GPU's two copy streams
-            e = hipStreamCreateWithFlags(&s->lanes[k]->up, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->lanes[k]->down, hipStreamNonBlocking);
-        }
         if (e != hipSuccess) {
             dpx_stream_destroy(s);
             return fail(DPX_ERR_HIP, "stream slab allocation failed: %s", hipGetErrorString(e));
         }
     }
+    if (s->path == DPX_STREAM_PATH_STAGED && !(o.path & DPX_STREAM_NO_PROBE))
+        for (int i = 0; i < n_ctx; ++i) separate_lane_streams(s, (size_t)i);
     if (n_ctx > 1) {
         for (int i = 0; i < n_ctx; ++i) {
             s->workers.emplace_back(new dpx_stream::Worker);
@@ -306,12 +328,14 @@ void dpx_stream_destroy(dpx_stream *s)
         if (b.done) (void)hipEventDestroy(b.done);
         if (b.ev_up) (void)hipEventDestroy(b.ev_up);
         if (b.ev_run) (void)hipEventDestroy(b.ev_run);
-        if (b.stream) (void)hipStreamDestroy(b.stream);
+        if (b.stream && b.owns_stream) (void)hipStreamDestroy(b.stream);
     }
     for (size_t i = 0; i < s->lanes.size(); ++i) {
         (void)hipSetDevice(s->ctxs[i]->device);
         if (s->lanes[i]->up) { (void)hipStreamSynchronize(s->lanes[i]->up); (void)hipStreamDestroy(s->lanes[i]->up); }
         if (s->lanes[i]->down) { (void)hipStreamSynchronize(s->lanes[i]->down); (void)hipStreamDestroy(s->lanes[i]->down); }
+        if (s->lanes[i]->run) { (void)hipStreamSynchronize(s->lanes[i]->run); (void)hipStreamDestroy(s->lanes[i]->run); }
+        for (hipStream_t st : s->lanes[i]->parked) (void)hipStreamDestroy(st);
     }
     delete s;
 }
@@ -331,6 +355,74 @@ int dpx_stream_acquire(dpx_stream *s, void **pinned_in, size_t *capacity_bytes)
 }  // extern "C"
 
 namespace {
+
+// The staged path's three streams of one GPU must not share a hardware queue.  The runtime deals streams out over a few
+// hardware queues (GPU_MAX_HW_QUEUES, 4 by default) by rules of its own, and what queues behind a copy in one stream — the
+// event record that releases the next stage — holds up every other stream on that queue: `up` and `down` on one queue is
+// H2D and D2H taking turns at the link (28 GB/s each way instead of 47: measured with the streams created back to back in
+// a fresh process, and with a stream per slab inside bench.py).  So the ring measures once, when it is created: two copies
+// each way on `up` and `down`, alone and together (sharing shows as the sum instead of the maximum), and a 16-byte launch
+// on `run` against each (sharing shows as the launch waiting for the copies).  A stream that shares is parked — kept, idle,
+// so that its replacement is dealt another queue — and replaced; at most eight rounds, ~2 ms each; the outcome is in
+// dpx_stream_describe.  Performance only: a ring whose streams still share is slow, never wrong.
+void separate_lane_streams(dpx_stream *s, size_t lane_index)
+{
+    dpx_stream::Lane &ln = *s->lanes[lane_index];
+    dpx_stream_slab &b = s->slabs[lane_index];                  // the GPU's first slab lends its buffers
+    if (hipSetDevice(b.ctx->device) != hipSuccess || !ln.up || !ln.run || !ln.down || !b.d_in || !b.d_out) return;
+    const size_t in_b = s->slab_bytes, out_b = s->slab_out;
+    const size_t nb = std::min<size_t>(std::min(in_b, out_b), (size_t)16 << 20) & ~(size_t)15;
+    if (nb < ((size_t)1 << 20)) return;
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); };
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    for (hipEvent_t &e : ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return;
+    auto up2 = [&] { for (int i = 0; i < 2; ++i) { (void)hipMemcpyAsync(b.d_in, b.h_in, nb, hipMemcpyHostToDevice, ln.up); (void)hipEventRecord(ev[0], ln.up); } };
+    auto down2 = [&] { for (int i = 0; i < 2; ++i) { (void)hipMemcpyAsync(b.h_out, b.d_out, nb, hipMemcpyDeviceToHost, ln.down); (void)hipEventRecord(ev[1], ln.down); } };
+    auto run1 = [&] { (void)dpx::launch_copy(b.d_in, static_cast<char *>(b.d_in) + 64, 16, ln.run); (void)hipEventRecord(ev[2], ln.run); };
+    auto replace = [&](hipStream_t &st) {
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) return false;
+        ln.parked.push_back(st);
+        st = fresh;
+        return true;
+    };
+    // how long a 16-byte launch on `probe` takes to come back while `busy` holds two copies: ~20 us on a queue of its own,
+    // the copies' ~600 us behind them
+    auto tiny = [&](hipStream_t st) { (void)dpx::launch_copy(b.d_in, static_cast<char *>(b.d_in) + 64, 16, st); (void)hipEventRecord(ev[2], st); };
+    auto held_up = [&](bool busy_is_up, hipStream_t busy, hipStream_t probe) {
+        const clk::time_point t = clk::now();
+        if (busy_is_up) up2(); else down2();
+        tiny(probe);
+        (void)hipEventSynchronize(ev[2]);
+        const double t_probe = secs(t);
+        (void)hipStreamSynchronize(busy);
+        const double t_busy = secs(t);
+        (void)hipStreamSynchronize(probe);
+        return t_probe > 0.5 * t_busy;
+    };
+    const bool debug = getenv("DPX_STREAM_DEBUG") != nullptr;
+    up2(); down2(); run1(); tiny(ln.up); tiny(ln.down);          // first use of the three streams, untimed
+    (void)hipDeviceSynchronize();
+    for (int round = 0; round < 8; ++round) {
+        ln.probes = round + 1;
+        const bool ud = held_up(true, ln.up, ln.down), du = held_up(false, ln.down, ln.up);
+        const bool ur = held_up(true, ln.up, ln.run), dr = held_up(false, ln.down, ln.run);
+        ln.shared_queue = ud || du || ur || dr;
+        if (debug) fprintf(stderr, "dpx_stream: lane %zu round %d: up holds down %d, down holds up %d, up holds run %d, down holds run %d\n",
+                           lane_index, round, ud, du, ur, dr);
+        if (!ln.shared_queue) break;
+        bool ok = true;
+        if (ur || dr) ok = replace(ln.run);
+        if ((ud || du) && ok) ok = replace(ln.down);
+        if (!ok) break;
+        run1(); down2(); tiny(ln.down);
+        (void)hipDeviceSynchronize();
+    }
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    for (size_t k = lane_index; k < s->slabs.size(); k += s->lanes.size()) s->slabs[k].stream = ln.run;
+}
 
 // Hands queued D2H copies of one GPU to the runtime, oldest first, each only once its predecessor has finished (`upto` >= 0:
 // everything up to and including that slab regardless — dpx_stream_next(k), which cannot wait for a copy nobody has issued).
@@ -602,7 +694,13 @@ int dpx_stream_get_stats(const dpx_stream *s, dpx_stream_stats *out)
 int dpx_stream_describe(const dpx_stream *s, uint32_t *path, int *numa_nodes, size_t cap, size_t *n_slabs)
 {
     if (!s) return fail(DPX_ERR_ARG, "bad argument");
-    if (path) *path = s->path | (s->copy_only ? DPX_STREAM_COPY_ONLY : 0u) | (s->paced ? 0u : DPX_STREAM_UNPACED);
+    if (path) {
+        *path = s->path | (s->copy_only ? DPX_STREAM_COPY_ONLY : 0u) | (s->paced ? 0u : DPX_STREAM_UNPACED);
+        int probes = 0;
+        bool shared = false;
+        for (const auto &ln : s->lanes) { probes = std::max(probes, ln->probes); shared = shared || ln->shared_queue; }
+        *path |= ((uint32_t)probes & 0xfu) << 16 | (shared ? DPX_STREAM_SHARED_QUEUE : 0u);
+    }
     if (n_slabs) *n_slabs = s->slabs.size();
     for (size_t k = 0; numa_nodes && k < cap && k < s->slabs.size(); ++k) numa_nodes[k] = s->slabs[k].numa_node;
     return DPX_OK;

@@ -188,7 +188,7 @@ class Stream:
     the outputs in order.  The sample counter is carried from slab to slab like `samplenr` (main.rs:60)."""
 
     def __init__(self, ctx, in_fmt, out_fmt, samplerate, samplenum=0, slab_bytes=8 << 20, n_slabs=3, path=None,
-                 copy_only=False, in_host_flags=0, out_host_flags=0, unpaced=False):
+                 copy_only=False, in_host_flags=0, out_host_flags=0, unpaced=False, no_probe=False):
         """ctx: one Context, or a list of Contexts (one per GPU; slab k runs on context k mod len(ctx), n_slabs slabs
         per context).  path / copy_only / *_host_flags: dpx_stream_options (measurement only; None = the library's default)."""
         self._lib = _lib_handle()
@@ -197,11 +197,11 @@ class Stream:
         self.in_fmt, self.out_fmt = fmt_code(in_fmt), fmt_code(out_fmt)
         self._h = C.c_void_p()
         arr = (C.c_void_p * len(self.ctxs))(*[c.handle.value for c in self.ctxs])
-        if path is None and not copy_only and not in_host_flags and not out_host_flags and not unpaced:
+        if path is None and not copy_only and not in_host_flags and not out_host_flags and not unpaced and not no_probe:
             check(self._lib.dpx_stream_create_multi(arr, len(self.ctxs), self.in_fmt, self.out_fmt, int(samplerate),
                                                     int(samplenum), int(slab_bytes), int(n_slabs), C.byref(self._h)))
         else:
-            opt = _lib.StreamOptions(_lib.STREAM_PATHS[path or "default"] | (_lib.STREAM_COPY_ONLY if copy_only else 0) | (_lib.STREAM_UNPACED if unpaced else 0),
+            opt = _lib.StreamOptions(_lib.STREAM_PATHS[path or "default"] | (_lib.STREAM_COPY_ONLY if copy_only else 0) | (_lib.STREAM_UNPACED if unpaced else 0) | (_lib.STREAM_NO_PROBE if no_probe else 0),
                                      int(in_host_flags), int(out_host_flags), 0)
             check(self._lib.dpx_stream_create_opts(arr, len(self.ctxs), self.in_fmt, self.out_fmt, int(samplerate),
                                                    int(samplenum), int(slab_bytes), int(n_slabs), C.byref(opt), C.byref(self._h)))
@@ -214,7 +214,8 @@ class Stream:
         check(self._lib.dpx_stream_describe(self._h, C.byref(path), nodes, n.value, C.byref(n)))
         names = {v: k for k, v in _lib.STREAM_PATHS.items()}
         return {"path": names[path.value & 0xff], "copy_only": bool(path.value & _lib.STREAM_COPY_ONLY),
-                "numa_nodes": list(nodes[: n.value])}
+                "unpaced": bool(path.value & _lib.STREAM_UNPACED), "probe_rounds": (path.value >> 16) & 0xf,
+                "streams_share_a_queue": bool(path.value & _lib.STREAM_SHARED_QUEUE), "numa_nodes": list(nodes[: n.value])}
 
     def next_view(self):
         """Waits for the oldest submitted slab; returns a VIEW of its pinned output (valid until release())."""

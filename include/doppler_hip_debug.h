@@ -136,6 +136,8 @@ int dpx_stream_get_stats(const dpx_stream *s, dpx_stream_stats *out);
 #define DPX_STREAM_PATH_STAGED_PER_SLAB 5u
 #define DPX_STREAM_COPY_ONLY 0x100u
 #define DPX_STREAM_UNPACED 0x200u
+#define DPX_STREAM_NO_PROBE 0x400u        /* STAGED: take the three streams of a GPU as the runtime deals them (A/B) */
+#define DPX_STREAM_SHARED_QUEUE 0x800u    /* dpx_stream_describe only: after the last probe round two of a GPU's streams still shared a hardware queue */
 typedef struct dpx_stream_options {
     uint32_t path;
     uint32_t in_host_flags, out_host_flags;
@@ -144,7 +146,7 @@ typedef struct dpx_stream_options {
 int dpx_stream_create_opts(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_fmt, uint32_t samplerate,
                            uint32_t samplenum0, size_t slab_bytes, int slabs_per_ctx, const dpx_stream_options *opt,
                            dpx_stream **stream);
-/* the path a ring runs on (one of the four above) and the NUMA node each slab's pinned buffers were placed on (-1: the caller's policy) */
+/* the path a ring runs on (one of the above | its flags | probe rounds of the staged path's streams << 16) and the NUMA node each slab's pinned buffers were placed on (-1: the caller's policy) */
 int dpx_stream_describe(const dpx_stream *s, uint32_t *path, int *numa_nodes, size_t cap, size_t *n_slabs);
 
 /* Same access pattern, no arithmetic: 16-byte non-temporal copy of n_bytes.

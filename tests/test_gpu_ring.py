@@ -79,11 +79,20 @@ def test_track_segments_through_the_ring(ctx, orc, path):
         st.close()
 
 
-def test_default_path_is_the_direct_one_and_the_environment_selects(ctx, orc, monkeypatch):
+def test_default_path_follows_the_slab_size_and_the_environment_selects(ctx, orc, monkeypatch):
+    """Small slabs (a live pipe's 8 KiB block) take the one-launch direct path, large ones the paced copy engines; in between
+    engine H2D against the kernel's own stores (dpx_stream.cpp: kDirectBelow, kStagedFrom)."""
     import doppler_amd
+    for slab_bytes, want in ((8192, "direct"), (1 << 16, "direct"), (1 << 20, "direct_out"), (2 << 20, "direct_out"),
+                             (4 << 20, "staged"), (16 << 20, "staged")):
+        st = doppler_amd.Stream(ctx, "i16", "i16", 1024000, slab_bytes=slab_bytes, n_slabs=2)
+        d = st.describe()
+        assert d["path"] == want and not d["unpaced"], (slab_bytes, d)
+        if want == "staged":
+            # the ring has made sure its three streams do not wait for each other (separate_lane_streams)
+            assert d["probe_rounds"] >= 1 and not d["streams_share_a_queue"], d
+        st.close()
     st = doppler_amd.Stream(ctx, "i16", "i16", 1024000, slab_bytes=1 << 16, n_slabs=2)
-    assert st.describe()["path"] == "direct"
-    st.close()
     monkeypatch.setenv("DPX_STREAM_PATH", "2")
     st = doppler_amd.Stream(ctx, "i16", "i16", 1024000, slab_bytes=1 << 16, n_slabs=2)
     assert st.describe()["path"] == "staged"
@@ -91,6 +100,25 @@ def test_default_path_is_the_direct_one_and_the_environment_selects(ctx, orc, mo
     monkeypatch.setenv("DPX_STREAM_PATH", "9")
     with pytest.raises(doppler_amd.DspError):
         doppler_amd.Stream(ctx, "i16", "i16", 1024000, slab_bytes=1 << 16, n_slabs=2)
+
+
+@pytest.mark.parametrize("kw", [dict(unpaced=True), dict(no_probe=True), dict(unpaced=True, no_probe=True)])
+def test_staged_path_without_pacing_or_probe_keeps_the_bytes(ctx, orc, kw):
+    """The A/B switches of the staged path (every D2H queued at submit time; streams as the runtime deals them) change the rate only."""
+    import doppler_amd
+    rate, shift = 1024000, 5001
+    slab_bytes, n_ring = 4 << 20, 5
+    per = slab_bytes // 4
+    sizes = [per] * 7 + [per - 12, 3, per]
+    x = make_iq("i16", sum(sizes), 55, full_scale=True)
+    st = doppler_amd.Stream(ctx, "i16", "i16", rate, slab_bytes=slab_bytes, n_slabs=n_ring, path="staged", **kw)
+    try:
+        got = drive(st, x, 4, [(m, [(m, float(shift))]) for m in sizes], n_ring)
+        want, sn = orc.segments_stream(x, "i16", "i16", [(sum(sizes), float(shift))], rate, threads=8)
+        assert st.samplenum == sn
+        assert_same_bytes(got, want, "i16", "staged ring %r" % (kw,))
+    finally:
+        st.close()
 
 
 @pytest.mark.parametrize("flags", [(NONCOHERENT, NONCOHERENT), (NONCOHERENT, 0), (0, NONCOHERENT), (NUMAUSER, NUMAUSER)])

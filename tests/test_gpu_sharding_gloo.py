@@ -127,6 +127,10 @@ def test_bench_multi_rank_code_path_on_a_shared_gpu(world):
     assert all(r_["avg_kernel_ms"] > 0 and "pci_bus_id" in r_ for r_ in line["per_rank"]), line["per_rank"]
     assert [p["peer"] for p in line["gather"]["per_peer"]] == list(range(1, world))
     assert "error" not in line["gather"]["per_gpu_d2h"], line["gather"]["per_gpu_d2h"]
+    # the N-device ring of the shipped command (dpx_stream_create_multi from rank 0's process; here: one GPU listed N times)
+    pr = line["gather"]["product_ring"]
+    assert "error" not in pr, pr
+    assert pr["devices"] == [0] * world and len(pr["slab_numa_nodes"]) == 3 * world and pr["Msamples_per_s"] > 1000, pr
     # tools/check_scale.py reads the line as it will read the driver's SCALE record, and names what a shared-GPU run gets
     # wrong BY CONSTRUCTION: gloo instead of RCCL, every rank on the same GPU (the numbers it flags besides mean nothing here)
     sys.path.insert(0, os.path.join(ROOT, "tools"))

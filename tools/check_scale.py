@@ -10,12 +10,18 @@ time chunks (reference src/main.rs:60: the whole carried state is one u32), so t
   process group    world_size_seen == N, backend nccl, N distinct pci_bus_id values
   gather           RCCL into rank 0 within 2x of (N-1) GiB over N-1 xGMI links of ~153 GB/s each, i.e. ~7-10 ms however many
                    peers; per peer within 2x of 1 GiB / 153 GB/s = 7 ms; per-GPU D2H within 2x of 1 GiB / 55 GB/s = 19.5 ms
+  product ring     gather.product_ring (dpx_stream_create_multi from one process, what `doppler --gpus N` runs on): N x the one-GPU
+                   ring's 45-47 GB/s each way while the GPUs' root complexes and the host's memory keep up — two sockets of
+                   DDR5 give ~2 x 300 GB/s of DMA in + out, so N = 8 (8 x 47 x 2 = 750 GB/s) is expected to fall short of 8x, and
+                   one Python producer thread (20-40 us per slab) caps the ring near 64 MiB / 30 us; slabs on the GPU's own NUMA node
 Exit status 0 when nothing is off, 1 otherwise (2: no bench line found)."""
 import json
 import sys
 
 PER_GPU = (0.80e6, 0.87e6)         # Msamples/s a single MI355X delivers on the headline (0.83-0.85 measured; margins for box spread)
 XGMI_GBPS, PCIE_GBPS = 153.0, 55.0
+RING_GBPS = (40.0, 49.0)           # the one-GPU slab ring, each way (profiles/r06_ring.md: 45.6-47.5 at 16-64 MiB slabs)
+HOST_DMA_GBPS = 600.0              # in + out, both sockets: where an 8-GPU ring is expected to run into the host's memory
 
 
 def bench_lines(obj):
@@ -90,6 +96,24 @@ def check_line(line, base_value=None):
             elif d and d.get("ms", 0) > 2 * (gib / PCIE_GBPS * 1e3) + 3:
                 off.append("per-GPU D2H %.1f ms, predicted ~%.0f ms (each GPU its own PCIe link at ~%d GB/s): shared root complexes or "
                            "slabs on the wrong NUMA node" % (d["ms"], gib / PCIE_GBPS * 1e3, PCIE_GBPS))
+        pr = (line.get("gather") or {}).get("product_ring")
+        if pr is None:
+            off.append("gather.product_ring missing: the N-device ring of the shipped command was not run")
+        elif "error" in pr:
+            off.append("product ring: %s" % pr["error"])
+        else:
+            per = pr.get("GB_per_s_each_way_per_device", 0)
+            want_lo = min(RING_GBPS[0], HOST_DMA_GBPS / 2 / n * 0.8)
+            if per < want_lo:
+                off.append("product ring %.1f GB/s each way per device (%.0f aggregate), predicted >= %.0f: %s" % (
+                    per, pr.get("GB_per_s_each_way_aggregate", 0), want_lo,
+                    "its streams still share a hardware queue" if pr.get("streams_share_a_queue") else
+                    "the producer thread (%.0f us per slab), shared root complexes, or the host's memory" % pr.get("submit_us_per_slab", 0)))
+            if per > RING_GBPS[1] * 1.1:
+                off.append("product ring %.1f GB/s per device is above one PCIe link: the devices listed are not distinct" % per)
+            nodes = pr.get("slab_numa_nodes") or []
+            if nodes and len(set(nodes)) == 1 and n >= 4 and nodes[0] >= 0:
+                off.append("every slab of the %d-GPU ring sits on NUMA node %d: half of the copies cross the socket link" % (n, nodes[0]))
     rf = line.get("roofline") or {}
     if rf and not 0.78 <= rf.get("frac", 0) <= 0.88:
         off.append("roofline.frac %.3f of rank 0 outside 0.78-0.88" % rf.get("frac", 0))

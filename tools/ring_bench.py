@@ -21,6 +21,7 @@ import doppler_amd  # noqa: E402
 
 FLAGS = {"none": 0, "noncoherent": 0x80000000, "wc": 0x4, "numauser": 0x20000000, "coherent": 0x40000000}
 BPS = {"i16": 4, "f32": 8}
+WARM_S = 0.0
 
 
 def flags_of(spec):
@@ -50,7 +51,7 @@ def reference_output(ctx, slab, it, ot, shift, rate):
 
 def run_ring(ctxs, it, ot, shift, rate, slab_bytes, n_slabs, total_bytes, path, copy_only, fin, fout, pattern, want_first):
     st = doppler_amd.Stream(ctxs, it, ot, rate, slab_bytes=slab_bytes, n_slabs=n_slabs, path=path.split(":")[0], copy_only=copy_only,
-                            in_host_flags=fin, out_host_flags=fout, unpaced=path.endswith(":unpaced"))
+                            in_host_flags=fin, out_host_flags=fout, unpaced=":unpaced" in path, no_probe=":noprobe" in path)
     try:
         total_slabs = n_slabs * len(ctxs)
         segs = [(slab_bytes // BPS[it], float(shift))]
@@ -71,6 +72,20 @@ def run_ring(ctxs, it, ot, shift, rate, slab_bytes, n_slabs, total_bytes, path, 
             st.release()
         for _ in range(total_slabs):
             st.acquire()
+        if WARM_S > 0:          # a process's first 0.2-0.3 s of heavy PCIe traffic hold one 30-50 ms stall (profiles/r06_ring.md)
+            tw = time.perf_counter()
+            for _ in range(total_slabs):
+                st.submit(slab_bytes, segs)
+            while time.perf_counter() - tw < WARM_S:
+                st.next_view()
+                st.release()
+                st.acquire()
+                st.submit(slab_bytes, segs)
+            for _ in range(total_slabs):
+                st.next_view()
+                st.release()
+            for _ in range(total_slabs):
+                st.acquire()
         t0 = time.perf_counter()
         for _ in range(total_slabs):
             st.submit(slab_bytes, segs)
@@ -111,7 +126,10 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--contexts", type=int, default=1, help="contexts on device 0 (a multi-GPU ring over one device)")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--warm-s", type=float, default=0.3, help="untimed cycling before every timed run")
     a = ap.parse_args()
+    global WARM_S
+    WARM_S = a.warm_s
     it, ot = a.pair.split(":")
     ctxs = [doppler_amd.Context(0) for _ in range(a.contexts)]
     rng = np.random.default_rng(7)
