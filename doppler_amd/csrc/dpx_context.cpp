@@ -268,6 +268,12 @@ void dpx_ctx_destroy(dpx_ctx *ctx)
     // does not answer may still be queued behind other work and poll them later — nothing of the context is freed under a
     // kernel that has not finished
     if (resident_stop_device(ctx) != DPX_OK || resident_stop(ctx) != DPX_OK) (void)hipDeviceSynchronize();
+    // whatever happened above, the process-wide device state never points at a context that is about to be freed
+    {
+        dpx_ctx *me = ctx;
+        ctx->dev->resident_owner.compare_exchange_strong(me, nullptr);
+        ctx->resident_running.store(false, std::memory_order_release);
+    }
     if (ctx->rstream) { (void)hipStreamSynchronize(ctx->rstream); (void)hipStreamDestroy(ctx->rstream); }
     if (ctx->rshared) (void)hipFree(ctx->rshared);
     if (ctx->stage_in) (void)hipFree(ctx->stage_in);
@@ -316,6 +322,7 @@ int dpx_set_options(dpx_ctx *ctx, const dpx_options *opt)
         const uint32_t ww = opt->walk_waves;
         if (ww != 0 && !dpx::walk_waves_ok(ww, false)) return fail(DPX_ERR_ARG, "walk_waves must be 2, 4, 5 or 8");
         if (opt->walk_span == 1 || opt->walk_span > 4096) return fail(DPX_ERR_ARG, "walk_span must be 0 (the planner's cut) or 2..4096 rows");
+        if (opt->sub_lg != 0 && opt->sub_lg < 12) return fail(DPX_ERR_ARG, "sub_lg must be 0 (the default), 12..47, or >= 48 (one launch whatever the length)");
     }
     ctx->tuning = tuning_of(opt);
     return DPX_OK;

@@ -107,12 +107,12 @@ int dpx_plan_segments(dpx_ctx *ctx, const dpx_segment *segs, size_t n_segs, uint
     p->host.final_samplenum = sn;
     append_segments(p->host, segs, n_segs, samplerate, sn, ctx->variant, ctx->periods);
     dpx::finalize(p->host, p->geom.tile(), ctx->choice, ctx->tuning);
+    // the device's lock from here to the end: no other thread's context starts a resident block kernel on this device
+    // between its being asked to leave and this plan's upload having finished (the upload would queue behind it)
+    std::unique_lock<std::recursive_mutex> lock(ctx->dev->mu);
     hipError_t e = hipSetDevice(ctx->device);
     int rc = e == hipSuccess ? DPX_OK : fail(DPX_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
-    if (rc == DPX_OK) {
-        std::lock_guard<std::recursive_mutex> lock(ctx->dev->mu);
-        rc = resident_stop_device(ctx);
-    }
+    if (rc == DPX_OK) rc = resident_stop_device(ctx);
     if (rc == DPX_OK && p->host.error) rc = fail(DPX_ERR_PLAN, "%s", p->host.error);
     if (rc == DPX_OK && p->host.n_samples) {
         rc = materialize(ctx, p->host, p->dev, p->fma, ctx->stream);
@@ -121,6 +121,7 @@ int dpx_plan_segments(dpx_ctx *ctx, const dpx_segment *segs, size_t n_segs, uint
             if (e != hipSuccess) rc = fail(DPX_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
         }
     }
+    lock.unlock();
     if (rc != DPX_OK) {
         dpx_plan_destroy(p);
         return rc;
@@ -156,7 +157,10 @@ void dpx_plan_destroy(dpx_plan *plan)
 {
     if (!plan) return;
     if (plan->dev.buf) {
+        // hipFree waits for the device: a resident block kernel (any context's) leaves first, under the device's lock
+        std::lock_guard<std::recursive_mutex> lock(plan->ctx->dev->mu);
         (void)hipSetDevice(plan->ctx->device);
+        (void)resident_stop_device(plan->ctx);
         release(plan->dev);
     }
     delete plan;
@@ -169,11 +173,9 @@ int dpx_run_device(dpx_plan *plan, const void *d_in, int in_fmt, void *d_out, in
     if (plan->host.n_samples == 0) return DPX_OK;
     if (!d_in || !d_out) return fail(DPX_ERR_ARG, "null device pointer");
     if (((uintptr_t)d_in | (uintptr_t)d_out) & 15u) return fail(DPX_ERR_ARG, "device pointers must be 16-byte aligned");
-    if (plan->ctx->dev->resident_owner.load(std::memory_order_acquire)) {   // (one load otherwise) a resident block kernel could hold up this launch's queue
-        std::lock_guard<std::recursive_mutex> lock(plan->ctx->dev->mu);
-        const int rc = resident_stop_device(plan->ctx);
-        if (rc != DPX_OK) return rc;
-    }
+    // the device's lock for the whole enqueue: a resident block kernel (which would hold up this launch's queue) is asked to
+    // leave, and no other thread's context starts one before the launches are in the queue (~40 ns when nothing contends)
+    DPX_ENTER(plan->ctx);
     return run_plan(plan->host, plan->dev, d_in, in_fmt, d_out, out_fmt, plan->fma, plan->geom, hip_stream);
 }
 

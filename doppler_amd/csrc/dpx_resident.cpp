@@ -73,6 +73,13 @@ int wait_parked(dpx_ctx *ctx, bool asked)
             for (auto &s : ctx->async_slots)
                 if (s.host) { ring(slot_ctl(s), dpx::kDoorExit, 0, 0, 0, 0); s.poisoned = true; }
             ctx->resident_on = false;
+            // the device is handed back: other contexts must neither call into this one (it may be destroyed next) nor fail
+            // their own launches on its account — theirs go per launch or start a kernel of their own, behind the stuck one
+            // at worst.  This context keeps resident_running until its slots are seen parked (slot_usable).
+            {
+                dpx_ctx *me = ctx;
+                ctx->dev->resident_owner.compare_exchange_strong(me, nullptr);
+            }
             return fail(DPX_ERR_HIP, "the resident block kernel does not leave");
         }
         cpu_relax();

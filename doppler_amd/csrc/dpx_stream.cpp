@@ -316,8 +316,15 @@ void dpx_stream_destroy(dpx_stream *s)
         w->cv.notify_all();
         if (w->th.joinable()) w->th.join();
     }
+    for (dpx_ctx *c : s->ctxs) {                     // hipFree / hipHostFree wait for the device: a resident block kernel leaves first
+        std::lock_guard<std::recursive_mutex> lock(c->dev->mu);
+        (void)hipSetDevice(c->device);
+        (void)resident_stop_device(c);
+    }
     for (dpx_stream_slab &b : s->slabs) {
-        if (b.ctx) (void)hipSetDevice(b.ctx->device);
+        if (!b.ctx) continue;
+        std::lock_guard<std::recursive_mutex> lock(b.ctx->dev->mu);
+        (void)hipSetDevice(b.ctx->device);
         if (b.stream) (void)hipStreamSynchronize(b.stream);
         if (b.done) (void)hipEventSynchronize(b.done);      // (recorded on the GPU's `down` stream when the output is staged)
         if (b.h_in) (void)hipHostFree(b.h_in);

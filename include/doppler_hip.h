@@ -38,7 +38,10 @@
 extern "C" {
 #endif
 
-#define DPX_ABI_VERSION 4
+/* 5 (round 6): dpx_stream_create_opts / dpx_stream_describe (doppler_hip_debug.h); dpx_options.reserved became sub_lg and is
+ * validated (round 5 changed its meaning without a bump: a caller that left garbage there is now refused, not obeyed);
+ * dpx_layout.f32_i16_by_tiles covers both mixed pairs.  No entry point of versions 1-4 changed its signature. */
+#define DPX_ABI_VERSION 5
 
 /* reference src/usage.rs:39-42  enum DataType { F32, I16 } */
 #define DPX_FMT_I16 0

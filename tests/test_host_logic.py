@@ -10,6 +10,8 @@ import doppler_amd
 from doppler_amd import _lib, engine, shard
 from helpers import oracle_counters
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 RATIOS = [(5000.0, 1024000), (-15000.0, 256000), (815000.0, 2400000), (0.0, 1024000), (9876.543, 1024000),
           (-5234.17, 1024000), (3.0, 1024000), (1.0, 3), (7.0, 2), (123456.0, 48000)]
 
@@ -31,12 +33,26 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert set(declared) == set(_lib._SIGNATURES), set(declared) ^ set(_lib._SIGNATURES)
-    assert doppler_amd.lib.dpx_abi_version() == 4
+    assert doppler_amd.lib.dpx_abi_version() == 5
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("dpx_")}
     assert exported == set(declared), exported ^ set(declared)
     assert os.path.getsize(_lib.LIB_PATH) < 4 * 1024 * 1024, "the library grew past 4 MB: which instantiations came back?"
+
+
+def test_only_the_product_library_ships():
+    """doppler_amd/lib travels to every GPU box with the tree: it holds libdoppler_hip.so and the objects it was linked from —
+    no A/B leftovers (round 5 shipped two 3.9 MB alternates there), and __graft_entry__.build() leaves it that way.  Helper
+    binaries of tools/ are built outside the tree (tools/build_tools.sh)."""
+    libdir = os.path.join(ROOT, "doppler_amd", "lib")
+    names = sorted(os.listdir(libdir))
+    assert [n for n in names if n.endswith(".so")] == ["libdoppler_hip.so"], names
+    assert all(n.endswith(".o") or n == "libdoppler_hip.so" for n in names), names
+    assert not os.path.exists(os.path.join(ROOT, "tools", "bin")), "tools/bin is back: build helpers with tools/build_tools.sh (into /tmp)"
+    import __graft_entry__
+    __graft_entry__.build()
+    assert sorted(os.listdir(libdir)) == names
 
 
 def test_no_cpu_fallback_anywhere():
