@@ -64,6 +64,13 @@ tests/cpp/test_planner_fuzz: tests/cpp/test_planner_fuzz.cpp $(CSRC)/dpx_planner
 planner-fuzz: tests/cpp/test_planner_fuzz
 	tests/cpp/test_planner_fuzz 300
 
+# the closed-form first reset against the candidate-by-candidate scan (host only)
+tests/cpp/test_find_reset: tests/cpp/test_find_reset.cpp $(CSRC)/dpx_planner.cpp $(CSRC)/dpx_simulate.cpp $(CSRC)/dpx_planner.h $(CSRC)/dpx_types.h
+	g++ -O2 -std=c++17 -ffp-contract=off -fno-fast-math -Wall -o $@ tests/cpp/test_find_reset.cpp $(CSRC)/dpx_planner.cpp $(CSRC)/dpx_simulate.cpp
+
+find-reset: tests/cpp/test_find_reset
+	tests/cpp/test_find_reset 1
+
 oracle:
 	$(MAKE) -C oracle all
 
@@ -71,4 +78,4 @@ clean:
 	rm -rf $(LIBDIR) $(BINDIR)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib cli oracle cpptest planner-fuzz clean
+.PHONY: all lib cli oracle cpptest planner-fuzz find-reset clean

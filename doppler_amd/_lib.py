@@ -76,6 +76,24 @@ def make_options(opts):
     return C.byref(o)
 
 
+def segments_array(segments):
+    """(n_samples, shift_hz) pairs -> (dpx_segment array pointer, count, keep-alive).  Through numpy: a replay's 600 segments
+    cost 0.4 ms as ctypes structure stores, 0.03 ms this way — it is on the one-shot path bench.py times as plan_ms."""
+    import numpy as np
+    segs = segments if isinstance(segments, (list, tuple)) else list(segments)
+    if len(segs) <= 4:                       # const mode's one segment per slab: plain structure stores are cheaper than numpy
+        small = (Segment * max(1, len(segs)))()
+        for i, (n, hz) in enumerate(segs):
+            small[i].n_samples = int(n)
+            small[i].shift_hz = float(hz)
+        return small, len(segs), small
+    arr = np.zeros(max(1, len(segs)), dtype=np.dtype([("n_samples", "<u8"), ("shift_hz", "<f4"), ("pad", "<u4")]))
+    if segs:
+        arr["n_samples"] = [s[0] for s in segs]
+        arr["shift_hz"] = [s[1] for s in segs]
+    return C.cast(arr.ctypes.data, C.POINTER(Segment)), len(segs), arr
+
+
 def declared_symbols(header=None):
     """Every function the public headers declare (parsed from the header text); header: one of HEADERS, default all."""
     names = set()
@@ -107,7 +125,9 @@ _SIGNATURES = {
     "dpx_ccexpf": (_i, [_vp, _vp, _sz]),
     "dpx_ccexpf_imag": (_i, [_vp, _vp, _sz]),
     "dpx_find_reset": (_i, [_f, _u32, _u32, _u64, _P(_u32), _P(_i)]),
+    "dpx_find_reset_scan": (_i, [_f, _u32, _u32, _u64, _P(_u32), _P(_i)]),
     "dpx_samplenum_after": (_i, [_f, _u32, _u32, _u64, _P(_u32)]),
+    "dpx_samplenum_after_segments": (_i, [_vp, _sz, _u32, _u32, _P(_u32)]),
     "dpx_plan_describe": (_i, [_P(Segment), _sz, _u32, _u32, _i, _P(Stretch), _sz, _P(_sz), _P(_u32)]),
     "dpx_plan_simulate": (_i, [_P(Segment), _sz, _u32, _u32, _i, _i, _i, _vp, _i, _i, _vp, _vp, _u64]),
     "dpx_plan_layout": (_i, [_P(Segment), _sz, _u32, _u32, _i, _i, _i, _vp, _P(Layout)]),

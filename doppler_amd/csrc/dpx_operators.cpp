@@ -290,6 +290,30 @@ int dpx_find_reset(float shift_hz, uint32_t samplerate, uint32_t n_start, uint64
     return DPX_OK;
 }
 
+int dpx_find_reset_scan(float shift_hz, uint32_t samplerate, uint32_t n_start, uint64_t max_scan,
+                        uint32_t *n_reset, int *found)
+{
+    if (!n_reset || !found) return fail(DPX_ERR_ARG, "bad argument");
+    uint32_t n1 = 0;
+    *found = dpx::find_reset_scan(dpx::ratio_of(shift_hz, samplerate), n_start, max_scan, &n1) ? 1 : 0;
+    *n_reset = n1;
+    return DPX_OK;
+}
+
+int dpx_samplenum_after_segments(const dpx_segment *segs, size_t n_segs, uint32_t samplerate, uint32_t samplenum0,
+                                 uint32_t *samplenum)
+{
+    if (!samplenum || (n_segs && !segs)) return fail(DPX_ERR_ARG, "bad argument");
+    uint32_t sn = samplenum0;
+    dpx::PeriodCache cache;
+    for (size_t i = 0; i < n_segs; ++i) {
+        dpx::PlanResult plan;                          // (the stretch list of one segment: a handful of entries, dropped at once)
+        dpx::plan_append(plan, dpx::ratio_of(segs[i].shift_hz, samplerate), segs[i].n_samples, sn, 1, &cache);
+    }
+    *samplenum = sn;
+    return DPX_OK;
+}
+
 int dpx_samplenum_after(float shift_hz, uint32_t samplerate, uint32_t samplenum0, uint64_t k,
                         uint32_t *samplenum)
 {

@@ -10,7 +10,6 @@
 #include <stdlib.h>
 
 #include <algorithm>
-#include <thread>
 #include <utility>
 
 namespace dpx {
@@ -36,8 +35,9 @@ bool is_reset(float ratio, uint32_t n)
     return product_is_integer(p);
 }
 
-// The scan is the planner's whole cost (a period is 10^4..10^6 candidates), so where the host has AVX2 it runs eight
-// candidates per instruction in blocks, and only a block that holds a reset is looked at candidate by candidate.  Every
+// The scan, candidate by candidate — the definition of the counter rule's reset points, the planner's whole cost in rounds
+// 1-5, and since round 6 what find_reset() is held against and falls back to for counters from 2^24 on.  Where the host has
+// AVX2 it runs eight candidates per instruction in blocks, and only a block that holds a reset is looked at candidate by candidate.  Every
 // candidate still gets exactly the reference's arithmetic: fl32(ratio * fl32(n)) — one IEEE multiply per lane, the
 // int -> f32 conversion in the current (nearest-even) rounding mode — and the same test as product_is_integer().
 __attribute__((target("avx2")))
@@ -64,7 +64,7 @@ static int block_has_reset_avx2(float ratio, uint32_t n0, int len)      // candi
 
 static const bool kHaveAvx2 = __builtin_cpu_supports("avx2");
 
-bool find_reset(float ratio, uint32_t n_start, uint64_t max_scan, uint32_t *n_reset)
+bool find_reset_scan(float ratio, uint32_t n_start, uint64_t max_scan, uint32_t *n_reset)
 {
     const uint64_t to_wrap = (1ULL << 32) - (uint64_t)n_start;
     const uint64_t span = std::min(max_scan, to_wrap);
@@ -83,6 +83,136 @@ bool find_reset(float ratio, uint32_t n_start, uint64_t max_scan, uint32_t *n_re
         }
     }
     return false;
+}
+
+// ---- the first reset without a scan (round 6).
+//
+// For n < 2^24 the counter converts exactly, so p = fl32(ratio * n) is the rounding of the EXACT product X = M n 2^E
+// (|ratio| = M 2^E, M < 2^24 an integer; the sign plays no part: rounding to nearest even is symmetric).  With
+// k = floor(log2 X) and E < 0, Q = 2^-E:
+//     k >= 23            every float is an integer: reset (unless the product overflows)
+//     k <  23            p is an integer I  <=>  |X - I| <= ulp(X) / 2 = 2^(k-24)   [ties go to I: its significand is even
+//                        in every binade below 2^23; I = 2^(k+1), the binade's upper end, included; I = 0 never: X >= 2^k]
+//                        <=>  (M n mod Q) in [0, T] or [Q - T, Q),  T = floor(Q 2^(k-24)) = floor(2^(s-24)),  s = floor(log2(M n))
+// Inside one binade the tolerance T is a constant and n runs over an interval, so the first reset in it is the smallest
+// x >= 0 with  l <= (a x mod Q) <= r  for a = M mod Q and an interval [l, r] that follows from where the binade starts:
+// the Euclid-like descent of first_in_window() below, O(log Q) steps whatever the period.  At most ~25 binades lie
+// between n_start and X >= 2^23; binades in which even the best approximation so far (the remainder sequence of
+// Euclid's algorithm on (Q, a): |q_i a - p_i Q|, the smallest distance any n < q_(i+1) reaches) stays outside the
+// tolerance are skipped without a descent.  Beyond 2^24 (ratios below ~3e-8 with nothing found yet: a shift of
+// centihertz at megasamples per second) the counter itself is rounded and the SIMD scan above takes over.
+// find_reset_scan is the definition; tests/cpp/test_planner_fuzz.cpp and tests/test_host_logic.py hold the two against
+// each other (every start below 2^24 of selected ratios, random ratios of every exponent, ties, subnormals, overflow).
+typedef unsigned __int128 u128;
+static constexpr uint64_t kNone = ~0ull;
+
+// smallest x >= 0 with l <= (a x mod m) <= r, or kNone.  0 <= a < m, 0 <= l <= r < m; results beyond `cap` are reported
+// as kNone (the caller's binade ends there: no need to finish the arithmetic exactly).
+static uint64_t first_in_window(uint64_t a, uint64_t m, uint64_t l, uint64_t r, uint64_t cap)
+{
+    if (l == 0) return 0;
+    if (a == 0) return kNone;
+    const uint64_t c = (l + a - 1) / a;
+    if ((u128)a * c <= r) return c <= cap ? c : kNone;
+    // no multiple of a inside [l, r]: a x - m y in [l, r] needs y >= 1, and y must put (m y mod a) into [-r, -l] mod a
+    const uint64_t l2 = (a - r % a) % a, r2 = (a - l % a) % a;
+    // x = ceil((l + m y) / a) <= cap  =>  y <= (a cap + a - l) / m: the descent only ever needs y up to there
+    const u128 ycap = ((u128)a * cap + a) / m + 1;
+    const uint64_t y = first_in_window(m % a, a, l2, r2, ycap > (u128)kNone - 1 ? kNone - 1 : (uint64_t)ycap);
+    if (y == kNone) return kNone;
+    const u128 x = ((u128)l + (u128)m * y + a - 1) / a;
+    return x <= cap ? (uint64_t)x : kNone;
+}
+
+// first n in [n_start, end) with n < 2^24 and fl32(ratio * n) an integer; *beyond = true when the search has to go on at
+// or past 2^24 (nothing found below; the scan continues there)
+static bool first_reset_exact(float ratio, uint64_t n_start, uint64_t end, uint32_t *n_reset, bool *beyond)
+{
+    *beyond = false;
+    uint32_t bits;
+    memcpy(&bits, &ratio, sizeof bits);
+    const uint32_t ef = (bits >> 23) & 0xffu, frac = bits & 0x7fffffu;
+    if (n_start >= end) return false;
+    if (ef == 0xffu) return false;                       // inf / nan: no product is an integer (0 * inf = nan as well)
+    if (n_start == 0 || (ef == 0 && frac == 0)) {        // n = 0, or ratio = +-0: the product is 0
+        *n_reset = (uint32_t)n_start;
+        return true;
+    }
+    const uint64_t M = ef ? (frac | 0x800000u) : frac;   // |ratio| = M * 2^E
+    const int E = ef ? (int)ef - 150 : -149;
+    constexpr uint64_t kExact = 1ull << 24;              // counters below convert to f32 exactly
+    if (n_start >= kExact) { *beyond = true; return false; }
+    const uint64_t stop = std::min(end, kExact);         // exclusive
+    if (E >= 0) {                                        // every product is an integer; only overflow (monotone in n) prevents a reset
+        if (is_reset(ratio, (uint32_t)n_start)) { *n_reset = (uint32_t)n_start; return true; }
+        return false;                                    // inf from here on, also beyond 2^24
+    }
+    if (-E > 62) {                                       // X < 2^24 * 2^24 * 2^-63: every product below 1/2, no reset below 2^24
+        *beyond = end > kExact;
+        return false;
+    }
+    const uint64_t Q = 1ull << -E;
+    const uint64_t a = M % Q;
+    // remainder sequence of Euclid on (Q, a): rem[i] = |q[i] a - p Q| is the smallest distance to a multiple of Q that any
+    // 1 <= n < q[i+1] reaches
+    uint64_t qs[96], rems[96];
+    int n_conv = 0;
+    {
+        uint64_t r0 = Q, r1 = a, q0 = 0, q1 = 1;
+        while (r1 != 0 && n_conv < 94) {
+            qs[n_conv] = q1;
+            rems[n_conv] = r1;
+            ++n_conv;
+            const uint64_t t = r0 / r1, r2 = r0 - t * r1;
+            const u128 q2 = (u128)q0 + (u128)t * q1;
+            r0 = r1; r1 = r2;
+            q0 = q1; q1 = q2 > (u128)1 << 40 ? 1ull << 40 : (uint64_t)q2;
+        }
+        qs[n_conv] = q1;                                 // the denominator at which the remainder reaches 0 (or the cut-off)
+        rems[n_conv] = r1;
+        ++n_conv;
+    }
+    uint64_t n = n_start;
+    int conv = 0;
+    while (n < stop) {
+        const uint64_t mn = M * n;                       // < 2^48
+        const int s = 63 - __builtin_clzll(mn);          // floor(log2(M n)); k = s + E
+        if (s + E >= 23) {                               // X >= 2^23: an integer unless it overflowed
+            if (!is_reset(ratio, (uint32_t)n)) return false;
+            *n_reset = (uint32_t)n;
+            return true;
+        }
+        // the binade's last n: M n < 2^(s+1)
+        const uint64_t n_last = std::min<uint64_t>(stop - 1, ((1ull << (s + 1)) - 1) / M);
+        if (s + E < -1) { n = n_last + 1; continue; }    // X < 1/2: no integer within half an ulp
+        const uint64_t T = s >= 24 ? 1ull << (s - 24) : 0;
+        // skip the binade if no n up to its end comes within T of a multiple of Q at all
+        while (conv + 1 < n_conv && qs[conv + 1] <= n_last) ++conv;
+        if (qs[conv] <= n_last && rems[conv] > T && conv + 1 < n_conv) { n = n_last + 1; continue; }
+        const uint64_t b = (uint64_t)(((u128)a * n + T) % Q);
+        uint64_t x;
+        if (b <= 2 * T) x = 0;
+        else x = first_in_window(a, Q, Q - b, Q - b + 2 * T, n_last - n);
+        if (x != kNone && x <= n_last - n) {
+            *n_reset = (uint32_t)(n + x);
+            return true;
+        }
+        n = n_last + 1;
+    }
+    *beyond = end > kExact && n >= kExact;
+    return false;
+}
+
+bool find_reset(float ratio, uint32_t n_start, uint64_t max_scan, uint32_t *n_reset)
+{
+    const uint64_t to_wrap = (1ULL << 32) - (uint64_t)n_start;
+    const uint64_t span = std::min(max_scan, to_wrap);
+    const uint64_t end = (uint64_t)n_start + span;
+    bool beyond = false;
+    if (first_reset_exact(ratio, n_start, end, n_reset, &beyond)) return true;
+    if (!beyond) return false;
+    const uint64_t from = std::max<uint64_t>(n_start, 1ull << 24);
+    return find_reset_scan(ratio, (uint32_t)from, end - from, n_reset);
 }
 
 // first reset from counter 1 on, remembered per ratio (bit pattern): the period of every steady stretch with that ratio.
@@ -123,33 +253,14 @@ uint32_t PeriodCache::period(float ratio, uint64_t limit)
     return scan_entry(it->second, ratio, limit);
 }
 
-// Periods of many ratios at once: the scans are independent of each other (only the lead-ins of plan_append depend on
-// the carried counter), so a long segment list — a track replay has one ratio per second of stream — is scanned on
-// several host threads before the sequential pass, which then finds every period in the cache.
+// Periods of many ratios at once.  Rounds 3-5 scanned them on up to 16 host threads before the sequential pass (a period was
+// 10^4..10^6 candidates tried one by one); with the closed form a period costs ~0.4 us, less than handing it to a thread,
+// so this only makes room and the sequential pass finds each period on demand.
 void PeriodCache::prefetch(const float *ratios, const uint64_t *counts, size_t n)
 {
-    struct Todo { Entry *e; float ratio; uint64_t limit; };
-    std::vector<Todo> todo;
-    if (n > kMaxEntries) return;                             // more ratios than the cache holds: plan_append scans on demand
-    make_room(n);
-    for (size_t i = 0; i < n; ++i) {
-        uint32_t bits;
-        memcpy(&bits, &ratios[i], sizeof bits);
-        if (first_reset.find(bits) != first_reset.end()) continue;
-        // every entry exists before the threads start, and the threads work through pointers to their own entries:
-        // the map itself is not touched while they run (node-based container: the pointers stay valid)
-        Entry *e = &first_reset.emplace(bits, Entry()).first->second;
-        todo.push_back({e, ratios[i], counts[i] + 1});
-    }
-    const size_t hw = std::max(1u, std::thread::hardware_concurrency());
-    const size_t n_threads = std::min<size_t>({hw, 16, todo.size() / 8});
-    if (n_threads < 2) return;                               // plan_append scans on demand
-    std::vector<std::thread> pool;
-    for (size_t t = 0; t < n_threads; ++t)
-        pool.emplace_back([&, t] {
-            for (size_t i = t; i < todo.size(); i += n_threads) scan_entry(*todo[i].e, todo[i].ratio, todo[i].limit);
-        });
-    for (std::thread &th : pool) th.join();
+    (void)ratios;
+    (void)counts;
+    if (n <= kMaxEntries) make_room(n);
 }
 
 static uint32_t lut_len_for(uint32_t period, uint64_t count, int variant)
@@ -171,8 +282,9 @@ static uint32_t theta_abs_bits(float ratio, uint32_t n)
     return b & 0x7fffffffu;
 }
 
-// first counter whose |theta| bits are >= bound (0xffffffff: none below 2^32 - 1); |theta| is monotone in n
-static uint32_t first_counter_reaching(float ratio, uint32_t bound)
+// first counter whose |theta| bits are >= bound (0xffffffff: none below 2^32 - 1); |theta| is monotone in n.
+// An estimate from the bound's value, then stepped to the exact boundary (1-3 evaluations; rounds 2-5 bisected: 32).
+uint32_t first_counter_reaching_bisect(float ratio, uint32_t bound)       // rounds 2-5's form: what the estimate-and-step form is held against
 {
     if (theta_abs_bits(ratio, 0xfffffffeu) < bound) return 0xffffffffu;
     uint32_t lo = 0, hi = 0xfffffffeu;                     // invariant: bits(hi) >= bound
@@ -182,6 +294,22 @@ static uint32_t first_counter_reaching(float ratio, uint32_t bound)
         else lo = mid + 1;
     }
     return lo;
+}
+
+uint32_t first_counter_reaching(float ratio, uint32_t bound)
+{
+    if (theta_abs_bits(ratio, 0xfffffffeu) < bound) return 0xffffffffu;
+    if (theta_abs_bits(ratio, 0) >= bound) return 0;
+    float bv;
+    memcpy(&bv, &bound, sizeof bv);
+    const double est = (double)bv / (6.283185307179586 * fabs((double)ratio));
+    uint32_t n = est >= 4294967294.0 ? 0xfffffffeu : est < 1.0 ? 1u : (uint32_t)est;
+    // |theta(n)| >= bound from the boundary on: walk down while the predecessor still reaches it, up while n does not
+    uint32_t steps = 0;
+    while (n > 0 && theta_abs_bits(ratio, n - 1) >= bound && ++steps < 64) --n;
+    while (theta_abs_bits(ratio, n) < bound && ++steps < 64) ++n;
+    if (steps >= 64) return first_counter_reaching_bisect(ratio, bound);      // an estimate far off (counters beyond 2^24 round)
+    return n;
 }
 
 static void emit(PlanResult &plan, uint64_t first, uint64_t count, float ratio, uint32_t n_start,

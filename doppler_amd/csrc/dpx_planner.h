@@ -25,6 +25,9 @@ bool is_reset(float ratio, uint32_t n);
 
 // first n in [n_start, n_start + max_scan) (not past 2^32-1) with is_reset; false if none
 bool find_reset(float ratio, uint32_t n_start, uint64_t max_scan, uint32_t *n_reset);
+// the same by trying every candidate (AVX2 where the host has it): the definition find_reset is held against, and what
+// find_reset itself falls back to for counters from 2^24 on
+bool find_reset_scan(float ratio, uint32_t n_start, uint64_t max_scan, uint32_t *n_reset);
 
 struct TableBuild {     // one corrector table to fill at plan time
     uint64_t off;       // pool entry index
@@ -103,6 +106,11 @@ struct PeriodCache {
     uint32_t period(float ratio, uint64_t limit);     // first reset in [1, limit), or 0
     void prefetch(const float *ratios, const uint64_t *counts, size_t n);   // scan many ratios on several threads
 };
+
+// first counter whose |theta| (as the kernels compute it: two separately rounded f32 products) reaches the f32 whose bits are
+// `bound`, 0xffffffff if none: where a stretch's correctors change their sincos path (DevSeg.n_plain / n_large / n_huge)
+uint32_t first_counter_reaching(float ratio, uint32_t bound);
+uint32_t first_counter_reaching_bisect(float ratio, uint32_t bound);
 
 // variant: 0 auto, 1 sincos per sample wherever the period allows (>= 4), 2 tables whenever they fit
 void plan_append(PlanResult &plan, float ratio, uint64_t count, uint32_t &samplenum, int variant, PeriodCache *cache = nullptr);

@@ -142,12 +142,9 @@ class Plan:
     def __init__(self, ctx, segments, samplerate, samplenum=0):
         self._lib = _lib_handle()
         self.ctx = ctx
-        arr = (_lib.Segment * max(1, len(segments)))()
-        for i, (n, hz) in enumerate(segments):
-            arr[i].n_samples = int(n)
-            arr[i].shift_hz = float(hz)
+        arr, n_segs, _keep = _lib.segments_array(segments)
         self._h = C.c_void_p()
-        check(self._lib.dpx_plan_segments(ctx.handle, arr, len(segments), int(samplerate), int(samplenum),
+        check(self._lib.dpx_plan_segments(ctx.handle, arr, n_segs, int(samplerate), int(samplenum),
                                           C.byref(self._h)))
         n = C.c_uint64()
         check(self._lib.dpx_plan_n_samples(self._h, C.byref(n)))
@@ -233,11 +230,8 @@ class Stream:
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(cap.value,))
 
     def submit(self, in_bytes, segments):
-        arr = (_lib.Segment * max(1, len(segments)))()
-        for i, (n, hz) in enumerate(segments):
-            arr[i].n_samples = int(n)
-            arr[i].shift_hz = float(hz)
-        check(self._lib.dpx_stream_submit(self._h, int(in_bytes), arr, len(segments)))
+        arr, n_segs, _keep = _lib.segments_array(segments)
+        check(self._lib.dpx_stream_submit(self._h, int(in_bytes), arr, n_segs))
 
     def pending(self):
         n = C.c_int()
@@ -293,10 +287,7 @@ def plan_describe(segments, samplerate, samplenum=0, variant=0):
     Returns (list of dict, final_samplenum). Needs no GPU."""
     lib = _lib_handle()
     segs = list(segments)
-    arr = (_lib.Segment * max(1, len(segs)))()
-    for i, (n, hz) in enumerate(segs):
-        arr[i].n_samples = int(n)
-        arr[i].shift_hz = float(hz)
+    arr, _n, _keep = _lib.segments_array(segs)
     n_out = C.c_size_t()
     fin = C.c_uint32()
     cap = 64
@@ -318,12 +309,8 @@ def plan_simulate(segments, samplerate, samplenum=0, block=0, vecs=0, variant=3,
     pair: the format pair of the launch being mirrored (a span launch cuts its grid per pair)."""
     lib = _lib_handle()
     segs = list(segments)
-    arr = (_lib.Segment * max(1, len(segs)))()
-    n = 0
-    for i, (cnt, hz) in enumerate(segs):
-        arr[i].n_samples = int(cnt)
-        arr[i].shift_hz = float(hz)
-        n += int(cnt)
+    arr, _n, _keep = _lib.segments_array(segs)
+    n = sum(int(cnt) for cnt, _ in segs)
     counters = np.zeros(n, dtype=np.uint32)
     writes = np.zeros(n, dtype=np.uint8)
     check(lib.dpx_plan_simulate(arr, len(segs), int(samplerate), int(samplenum), block, vecs, variant,
@@ -335,10 +322,7 @@ def plan_layout(segments, samplerate, samplenum=0, block=0, vecs=0, variant=3, o
     """Host-only: how a plan is laid out over the kernels (dict of the dpx_layout fields). Needs no GPU."""
     lib = _lib_handle()
     segs = list(segments)
-    arr = (_lib.Segment * max(1, len(segs)))()
-    for i, (cnt, hz) in enumerate(segs):
-        arr[i].n_samples = int(cnt)
-        arr[i].shift_hz = float(hz)
+    arr, _n, _keep = _lib.segments_array(segs)
     lay = _lib.Layout()
     check(lib.dpx_plan_layout(arr, len(segs), int(samplerate), int(samplenum), block, vecs, variant,
                               _lib.make_options(options), C.byref(lay)))
@@ -351,6 +335,24 @@ def find_reset(shift_hz, samplerate, n_start, max_scan):
     found = C.c_int()
     check(lib.dpx_find_reset(float(shift_hz), int(samplerate), int(n_start), int(max_scan), C.byref(n), C.byref(found)))
     return n.value if found.value else None
+
+
+def find_reset_scan(shift_hz, samplerate, n_start, max_scan):
+    """The same by trying every candidate (the definition find_reset is held against)."""
+    lib = _lib_handle()
+    n = C.c_uint32()
+    found = C.c_int()
+    check(lib.dpx_find_reset_scan(float(shift_hz), int(samplerate), int(n_start), int(max_scan), C.byref(n), C.byref(found)))
+    return n.value if found.value else None
+
+
+def samplenum_after_segments(segments, samplerate, samplenum0=0):
+    """Counter after a list of (n_samples, shift_hz) segments (closed form per segment, one call)."""
+    lib = _lib_handle()
+    arr, n_segs, _keep = _lib.segments_array(segments)
+    n = C.c_uint32()
+    check(lib.dpx_samplenum_after_segments(arr, n_segs, int(samplerate), int(samplenum0), C.byref(n)))
+    return n.value
 
 
 def samplenum_after(shift_hz, samplerate, samplenum0, k):

@@ -51,10 +51,7 @@ def segments_for_chunk(segments, lo, hi):
 
 def seed_for_segments(segments_before, samplerate, samplenum0=0):
     """Counter after a piecewise-constant prefix (track mode), via the closed form per segment."""
-    sn = samplenum0
-    for n, hz in segments_before:
-        sn = engine.samplenum_after(hz, samplerate, sn, n)
-    return sn
+    return engine.samplenum_after_segments(segments_before, samplerate, samplenum0)
 
 
 def ordered_gather(local, sizes, dst=0, group=None):

@@ -18,13 +18,21 @@ extern "C" {
 /* ------------------------------------------------- host-side counter algebra
  * Closed form of the counter rule dsp.rs:125-130 (pure host integer/f32 code). */
 
-/* first n >= n_start with fract(fl32(ratio*fl32(n))) == 0, scanning at most
- * max_scan candidates; *found = 0 if none in range. ratio = shift_hz/(f32)samplerate. */
+/* first n in [n_start, n_start + max_scan) with fract(fl32(ratio*fl32(n))) == 0; *found = 0 if none in range.
+ * ratio = shift_hz/(f32)samplerate.  Since round 6 without a scan for counters below 2^24 (an Euclid-like descent per
+ * binade of the product: csrc/dpx_planner.cpp, ~0.4 us whatever the period); dpx_find_reset_scan tries every candidate
+ * (the definition: rounds 1-5's implementation, kept as the checker and for counters from 2^24 on). */
 int dpx_find_reset(float shift_hz, uint32_t samplerate, uint32_t n_start, uint64_t max_scan,
                    uint32_t *n_reset, int *found);
+int dpx_find_reset_scan(float shift_hz, uint32_t samplerate, uint32_t n_start, uint64_t max_scan,
+                        uint32_t *n_reset, int *found);
 /* value of the counter after `k` samples starting from samplenum0 (constant shift) */
 int dpx_samplenum_after(float shift_hz, uint32_t samplerate, uint32_t samplenum0, uint64_t k,
                         uint32_t *samplenum);
+/* ... after a whole list of constant-shift segments (what a rank of a time-chunk sharded run needs for the chunks before
+ * its own: the seed of its first sample, reference src/main.rs:60 carried by closed form instead of by running the stream) */
+int dpx_samplenum_after_segments(const dpx_segment *segs, size_t n_segs, uint32_t samplerate, uint32_t samplenum0,
+                                 uint32_t *samplenum);
 
 /* ------------------------------------------------ track mode, host side (N2)
  * Host-only.  The per-block shift schedule of `doppler track --time` (reference

@@ -45,13 +45,18 @@ def test_check_scale_names_what_is_off(tmp_path):
     args = argparse.Namespace(steps=300, warmup=10)
     n = bench.N_SAMPLES
 
-    def line(world, kernel_ms=0.320, slow_rank=None, gather_ms=8.0):
+    def line(world, kernel_ms=0.320, slow_rank=None, gather_ms=8.0, ring_per_device=46.0, ring_nodes=None, shared=False):
         per_rank = [dict(rank=r, device=r, pci_bus_id="0000:%02x:00.0" % (5 + r), avg_kernel_ms=kernel_ms * (1.12 if r == slow_rank else 1.0),
                          timed_region_s=0.0962) for r in range(world)]
         worst = max(p["avg_kernel_ms"] for p in per_rank)
         ln = bench.build_result(args, world, n, elapsed=300 * worst * 1e-3, avg_kernel_ms=kernel_ms,
                                 gather={"ms": gather_ms, "bytes_per_rank": 4 * n, "per_peer": [{"peer": p, "ms": 7.1, "GB_per_s": 151.0} for p in range(1, world)],
-                                        "per_gpu_d2h": {"ms": 20.1}} if world > 1 else None, per_rank=per_rank)
+                                        "per_gpu_d2h": {"ms": 20.1},
+                                        "product_ring": {"devices": list(range(world)), "GB_per_s_each_way_per_device": ring_per_device,
+                                                         "GB_per_s_each_way_aggregate": ring_per_device * world, "submit_us_per_slab": 21.0,
+                                                         "streams_share_a_queue": shared, "path": "staged",
+                                                         "slab_numa_nodes": ring_nodes or [(k % world) * 2 // world for k in range(3 * world)]}}
+                                if world > 1 else None, per_rank=per_rank)
         ln["backend"], ln["world_size_seen"] = ("nccl", world) if world > 1 else (None, 1)
         return json.loads(json.dumps(ln))
 
@@ -72,6 +77,17 @@ def test_check_scale_names_what_is_off(tmp_path):
     slow_peer = copy.deepcopy(line(4))
     slow_peer["gather"]["per_peer"][1]["ms"] = 30.0
     assert any("peer 2" in x for x in check_scale.check_line(slow_peer))
+    # the N-device ring of the shipped command: slow because its streams share a queue / for another reason, all slabs on one node, missing
+    f = " | ".join(check_scale.check_line(line(4, ring_per_device=27.0, shared=True)))
+    assert "product ring 27.0 GB/s" in f and "share a hardware queue" in f, f
+    f = " | ".join(check_scale.check_line(line(2, ring_per_device=20.0)))
+    assert "product ring 20.0 GB/s" in f and "producer thread" in f, f
+    assert check_scale.check_line(line(8, ring_per_device=33.0)) == []          # eight GPUs are expected to run into the host's memory
+    f = " | ".join(check_scale.check_line(line(8, ring_nodes=[0] * 24)))
+    assert "NUMA node 0" in f, f
+    gone = line(2)
+    del gone["gather"]["product_ring"]
+    assert any("product_ring missing" in x for x in check_scale.check_line(gone))
     q = tmp_path / "SCALE_skipped.json"
     q.write_text(json.dumps({"skipped": True, "reason": "no 8-GPU node"}))
     assert check_scale.main([str(q)]) == 2

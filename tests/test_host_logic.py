@@ -270,6 +270,19 @@ def test_planner_fuzz_under_sanitizers():
     assert "ok" in r.stdout
 
 
+def test_closed_form_first_reset_equals_the_candidate_scan():
+    """tests/cpp/test_find_reset.cpp: dpx::find_reset (round 6: an Euclid-like descent per binade of the product, no scan below
+    2^24) against dpx::find_reset_scan (every candidate tried with the arithmetic of dsp.rs:125-130) on ~280 000 queries —
+    named ratios from every start, random ratios of every exponent and sign, exact ties and their neighbours, dyadic
+    ratios, subnormals, overflow, zero / inf / nan, windows across 2^24."""
+    import subprocess
+    r = subprocess.run(["make", "-C", ROOT, "tests/cpp/test_find_reset"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_find_reset"), "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "equal to the scan" in r.stdout
+
+
 def test_chunk_sharding_seeds(orc):
     n = 2048 * 37 + 555
     for world in (1, 2, 3, 8):
