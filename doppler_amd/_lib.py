@@ -138,6 +138,7 @@ _SIGNATURES = {
     "dpx_plan_const": (_i, [_vp, _f, _u32, _u32, _u64, _P(_vp)]),
     "dpx_plan_segments": (_i, [_vp, _P(Segment), _sz, _u32, _u32, _P(_vp)]),
     "dpx_plan_n_samples": (_i, [_vp, _P(_u64)]),
+    "dpx_plan_timing": (_i, [_vp, _P(C.c_double)]),
     "dpx_set_resident": (_i, [_vp, _i]),
     "dpx_resident_stats": (_i, [_vp, _P(_u64), _P(_u64)]),
     "dpx_resident_info": (_i, [_vp, _vp]),

@@ -103,14 +103,19 @@ void append_segments(dpx::PlanResult &plan, const dpx_segment *segs, size_t n_se
 // `plan` must have been finalize()d for geometry `g`.
 int materialize(dpx_ctx *ctx, const dpx::PlanResult &plan, DevPlan &dev, bool fma, hipStream_t st)
 {
+    // device buffer: stretches | hints | leftover ranges | their hints | spans | span index   (one upload)
+    //                | span descriptors, one per group of 8 workgroups (written on the device) | corrector tables
     const size_t seg_bytes = align256(plan.segs.size() * sizeof(dpx::DevSeg));
     const size_t hint_bytes = align256(plan.hint.size() * sizeof(uint32_t));
-    const size_t n_wdesc = plan.walk.empty() ? 0 : plan.walk_hint.size();
-    const size_t walk_bytes = align256(n_wdesc * sizeof(dpx::WalkSeg));
     const size_t left_bytes = align256(plan.left.size() * sizeof(dpx::LeftRange));
     const size_t lhint_bytes = align256(plan.left_hint.size() * sizeof(uint32_t));
+    const size_t n_wdesc = plan.walk.empty() ? 0 : plan.walk_hint.size();
+    const size_t span_bytes = align256(n_wdesc ? plan.walk.size() * sizeof(dpx::WalkSeg) : 0);
+    const size_t index_bytes = align256(n_wdesc * sizeof(uint32_t));
+    const size_t walk_bytes = align256(n_wdesc * sizeof(dpx::WalkSeg));
     const size_t lut_bytes = align256(plan.lut_entries * 8 + 64);
-    const size_t need = seg_bytes + hint_bytes + walk_bytes + left_bytes + lhint_bytes + lut_bytes;
+    const size_t image_bytes = seg_bytes + hint_bytes + left_bytes + lhint_bytes + span_bytes + index_bytes;
+    const size_t need = image_bytes + walk_bytes + lut_bytes;
     if (need > dev.cap) {
         if (dev.buf) {
             DPX_HIP(hipStreamSynchronize(st));
@@ -123,27 +128,32 @@ int materialize(dpx_ctx *ctx, const dpx::PlanResult &plan, DevPlan &dev, bool fm
         dev.cap = cap;
     }
     char *base = static_cast<char *>(dev.buf);
-    dev.segs = reinterpret_cast<dpx::DevSeg *>(base);
-    dev.hint = reinterpret_cast<uint32_t *>(base + seg_bytes);
-    char *p = base + seg_bytes + hint_bytes;
-    dev.walk = reinterpret_cast<dpx::WalkSeg *>(p);          p += walk_bytes;
+    char *p = base;
+    dev.segs = reinterpret_cast<dpx::DevSeg *>(p);           p += seg_bytes;
+    dev.hint = reinterpret_cast<uint32_t *>(p);              p += hint_bytes;
     dev.left = reinterpret_cast<dpx::LeftRange *>(p);        p += left_bytes;
     dev.left_hint = reinterpret_cast<uint32_t *>(p);         p += lhint_bytes;
+    char *d_spans = p;                                       p += span_bytes;
+    char *d_index = p;                                       p += index_bytes;
+    dev.walk = reinterpret_cast<dpx::WalkSeg *>(p);          p += walk_bytes;
     dev.lut = p;
     // one host image of all the small tables, one copy (every hipMemcpyAsync from pageable memory costs 5-8 us)
-    const size_t image_bytes = seg_bytes + hint_bytes + walk_bytes + left_bytes + lhint_bytes;
     dev.image.assign(image_bytes, 0);
     char *img = dev.image.data();
     auto put = [&](size_t off, const void *src, size_t bytes) { if (bytes) memcpy(img + off, src, bytes); };
     size_t off = 0;
     put(off, plan.segs.data(), plan.segs.size() * sizeof(dpx::DevSeg));              off += seg_bytes;
     put(off, plan.hint.data(), plan.hint.size() * sizeof(uint32_t));                 off += hint_bytes;
-    // the chunk descriptor of every group of 8 workgroups, so that a workgroup finds its own with one scalar load
-    for (size_t h = 0; h < n_wdesc; ++h) memcpy(img + off + h * sizeof(dpx::WalkSeg), &plan.walk[plan.walk_hint[h]], sizeof(dpx::WalkSeg));
-    off += walk_bytes;
     put(off, plan.left.data(), plan.left.size() * sizeof(dpx::LeftRange));           off += left_bytes;
-    put(off, plan.left_hint.data(), plan.left_hint.size() * sizeof(uint32_t));
+    put(off, plan.left_hint.data(), plan.left_hint.size() * sizeof(uint32_t));       off += lhint_bytes;
+    if (n_wdesc) {
+        put(off, plan.walk.data(), plan.walk.size() * sizeof(dpx::WalkSeg));         off += span_bytes;
+        put(off, plan.walk_hint.data(), n_wdesc * sizeof(uint32_t));
+    }
     DPX_HIP(hipMemcpyAsync(base, img, image_bytes, hipMemcpyHostToDevice, st));
+    // the descriptor of every group of 8 workgroups, so that a workgroup finds its own with one scalar load: spans[index[group]]
+    if (n_wdesc && dpx::launch_expand_walk(d_spans, d_index, dev.walk, (uint32_t)n_wdesc, st) != DPX_OK)
+        return fail(DPX_ERR_HIP, "descriptor launch failed: %s", hipGetErrorString(hipGetLastError()));
     for (const dpx::TableBuild &t : plan.tables) {
         int rc = dpx::launch_build_lut(static_cast<char *>(dev.lut) + (size_t)t.off * 8, t.period, t.n_first,
                                        t.n_entries, t.ratio, fma, st);

@@ -137,6 +137,7 @@ struct dpx_plan {
     dpx::LaunchGeom geom;
     bool fma = true;
     dpx_api::DevPlan dev;
+    double t_append_us = 0, t_finalize_us = 0, t_upload_us = 0;   // where dpx_plan_segments spent its time (dpx_plan_timing)
 };
 
 namespace dpx_api {

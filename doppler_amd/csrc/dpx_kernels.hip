@@ -1204,6 +1204,17 @@ __global__ __launch_bounds__(kBlock) void copy_kernel(const u32x4 *__restrict__ 
     if (i < n_vec) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
 }
 
+// A span launch of many matrices finds its descriptor with ONE scalar load: desc[blockIdx.x >> kWalkHintShift], i.e. the list
+// of spans written out once per group of 8 workgroups (2.6 MB for a 600 s replay).  The host uploads the spans themselves
+// (92 KB) and the index of every group (165 KB); this writes the rest on the device, 16 bytes per lane (round 6: the
+// 2.6 MB went over PCIe from pageable memory before, 240 of a plan's 840 us).
+__global__ __launch_bounds__(kBlock) void expand_walk_kernel(const u32x4 *__restrict__ spans, const uint32_t *__restrict__ index,
+                                                             u32x4 *__restrict__ desc, uint32_t n_desc)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_desc * 4u) desc[i] = spans[index[i >> 2] * 4u + (i & 3u)];
+}
+
 // dsp.rs:85-99 on its own (the fused kernel never materialises this)
 __global__ __launch_bounds__(kBlock) void unpack_i16_kernel(const uint32_t *__restrict__ in,
                                                             float2 *__restrict__ out, uint64_t n)
@@ -1421,6 +1432,15 @@ static int aux_grid(uint64_t n)
 {
     uint64_t b = (n + kBlock - 1) / kBlock;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+int launch_expand_walk(const void *d_spans, const void *d_index, void *d_desc, uint32_t n_desc, void *stream)
+{
+    static_assert(sizeof(WalkSeg) == 4 * sizeof(u32x4), "a descriptor is four 16-byte vectors");
+    if (n_desc == 0) return DPX_OK;
+    expand_walk_kernel<<<(n_desc * 4u + kBlock - 1) / kBlock, kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const u32x4 *>(d_spans), static_cast<const uint32_t *>(d_index), static_cast<u32x4 *>(d_desc), n_desc);
+    return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;
 }
 
 int launch_copy(const void *d_in, void *d_out, uint64_t n_bytes, void *stream)

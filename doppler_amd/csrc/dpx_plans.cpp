@@ -105,8 +105,15 @@ int dpx_plan_segments(dpx_ctx *ctx, const dpx_segment *segs, size_t n_segs, uint
     p->fma = ctx->fma;
     uint32_t sn = samplenum0;
     p->host.final_samplenum = sn;
+    using clk = std::chrono::steady_clock;
+    auto us_since = [](clk::time_point t) { return std::chrono::duration<double, std::micro>(clk::now() - t).count(); };
+    clk::time_point t0 = clk::now();
     append_segments(p->host, segs, n_segs, samplerate, sn, ctx->variant, ctx->periods);
+    p->t_append_us = us_since(t0);
+    t0 = clk::now();
     dpx::finalize(p->host, p->geom.tile(), ctx->choice, ctx->tuning);
+    p->t_finalize_us = us_since(t0);
+    t0 = clk::now();
     // the device's lock from here to the end: no other thread's context starts a resident block kernel on this device
     // between its being asked to leave and this plan's upload having finished (the upload would queue behind it)
     std::unique_lock<std::recursive_mutex> lock(ctx->dev->mu);
@@ -122,6 +129,7 @@ int dpx_plan_segments(dpx_ctx *ctx, const dpx_segment *segs, size_t n_segs, uint
         }
     }
     lock.unlock();
+    p->t_upload_us = us_since(t0);
     if (rc != DPX_OK) {
         dpx_plan_destroy(p);
         return rc;
@@ -143,6 +151,15 @@ int dpx_plan_n_samples(const dpx_plan *plan, uint64_t *n_samples)
 {
     if (!plan || !n_samples) return fail(DPX_ERR_ARG, "bad argument");
     *n_samples = plan->host.n_samples;
+    return DPX_OK;
+}
+
+int dpx_plan_timing(const dpx_plan *plan, double out_us[3])
+{
+    if (!plan || !out_us) return fail(DPX_ERR_ARG, "bad argument");
+    out_us[0] = plan->t_append_us;
+    out_us[1] = plan->t_finalize_us;
+    out_us[2] = plan->t_upload_us;
     return DPX_OK;
 }
 

@@ -281,6 +281,8 @@ int launch_span(const void *d_in, int in_fmt, void *d_out, int out_fmt, const De
 int launch_build_lut(void *d_lut_entries, uint32_t period, uint32_t n_first, uint32_t n_entries,
                      float ratio, bool fma, void *stream);
 int launch_copy(const void *d_in, void *d_out, uint64_t n_bytes, void *stream);
+// desc[h] = spans[index[h]] for h < n_desc (the span launch's descriptor per group of 8 workgroups, written on the device)
+int launch_expand_walk(const void *d_spans, const void *d_index, void *d_desc, uint32_t n_desc, void *stream);
 int launch_unpack_i16(const void *d_in, void *d_out, uint64_t n_samples, void *stream);
 int launch_pack_i16(const void *d_in, void *d_out, uint64_t n_samples, void *stream, int legacy_cast = 0);
 int launch_ccexpf_imag(void *d_z, uint64_t n, bool fma, void *stream);

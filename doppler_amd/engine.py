@@ -153,6 +153,12 @@ class Plan:
         check(self._lib.dpx_plan_final_samplenum(self._h, C.byref(sn)))
         self.final_samplenum = sn.value
 
+    def timing(self):
+        """Microseconds dpx_plan_segments spent on: the stretch list, the launch layout, the device image (upload + wait)."""
+        t = (C.c_double * 3)()
+        check(self._lib.dpx_plan_timing(self._h, t))
+        return {"stretch_list_us": round(t[0], 1), "layout_us": round(t[1], 1), "device_image_us": round(t[2], 1)}
+
     def run(self, d_in, in_fmt, d_out, out_fmt, stream=0):
         """Asynchronous launch on `stream` (a hipStream_t value; 0 = default stream)."""
         check(self._lib.dpx_run_device(self._h, C.c_void_p(d_in), fmt_code(in_fmt), C.c_void_p(d_out),

@@ -87,6 +87,9 @@ int dpx_plan_layout(const dpx_segment *segs, size_t n_segs, uint32_t samplerate,
                     int block, int vecs, int variant, const struct dpx_options *opt, dpx_layout *out);
 
 int dpx_plan_n_samples(const dpx_plan *plan, uint64_t *n_samples);
+/* where dpx_plan_segments / dpx_plan_const spent its time, microseconds: [0] stretch list (the counter rule's closed form per
+ * segment), [1] launch layout (kernel choice, spans, hint tables), [2] device image: build, upload, table kernels, the wait */
+int dpx_plan_timing(const dpx_plan *plan, double out_us[3]);
 
 /* The resident block kernel behind dpx_shift_block / dpx_shift_block_async (on by default; DPX_RESIDENT=0 in the environment
  * turns it off for every context): on = 0 sends every block through a launch of its own again (round 3's path, kept as the
