@@ -328,7 +328,7 @@ def drive_ring(ctxs, slab_bytes, n_slabs, total_bytes, fill, check=None, warm_s=
         st.close()
 
 
-def product_ring(devices, seconds=PRODUCT_RING_S):
+def product_ring(devices, seconds=PRODUCT_RING_S, gather=None):
     """gather.product_ring (N > 1): dpx_stream_create_multi over all N devices from ONE process, driven from pinned memory
     for about `seconds`: aggregate rate, the rate per device, where every slab's pinned buffers live."""
     import numpy as np
@@ -343,7 +343,10 @@ def product_ring(devices, seconds=PRODUCT_RING_S):
 
         # sized by time: about `seconds` at the single-GPU ring's rate per device
         total = int(seconds * 45e9 * len(set(devices))) // slab * slab
-        dt, nb, desc, stats, win = drive_ring(ctxs, slab, PRODUCT_RING_SLABS, total, fill, None, warm_s=RING_WARM_S)
+        kw = {"gather": gather} if gather else {}
+        if gather == "rccl":
+            total = int(seconds * 45e9) // slab * slab          # every output byte leaves through the first GPU's link
+        dt, nb, desc, stats, win = drive_ring(ctxs, slab, PRODUCT_RING_SLABS, total, fill, None, warm_s=RING_WARM_S, **kw)
         n = len(ctxs)
         return {"what": "dpx_stream_create_multi over %d device(s) from one process (what `doppler --gpus N` runs on): %d slabs of %d MiB per "
                         "GPU in pinned host memory, headline shift, i16 -> i16, slab k on GPU k mod N, per-GPU D2H, outputs in order" %
@@ -351,7 +354,7 @@ def product_ring(devices, seconds=PRODUCT_RING_S):
                 "devices": devices, "Msamples_per_s": round(nb / 4 / dt / 1e6, 1), "seconds": round(dt, 3),
                 "GB_per_s_each_way_aggregate": round(nb / dt / 1e9, 2), "GB_per_s_each_way_per_device": round(nb / dt / 1e9 / n, 2),
                 "GB_per_s_in_50ms_windows": {"min": win[0], "median": win[1]},
-                "path": desc["path"], "stream_probe_rounds": desc.get("probe_rounds"), "streams_share_a_queue": desc.get("streams_share_a_queue"),
+                "gather": desc.get("gather"), "path": desc["path"], "stream_probe_rounds": desc.get("probe_rounds"), "streams_share_a_queue": desc.get("streams_share_a_queue"),
                 "slab_numa_nodes": desc["numa_nodes"], "submit_us_per_slab": round(stats["total_us"] / max(1, stats["slabs"]), 2),
                 "producer": "one Python thread: acquire / submit / next / release per slab (%.0f us of dpx_stream_submit per slab)" %
                             (stats["total_us"] / max(1, stats["slabs"]))}
@@ -492,9 +495,11 @@ def build_result(args, world, n, elapsed, avg_kernel_ms, gather, plan_ms=None, o
         roof["sustained_launches"] = sustained["launches"]
         roof["avg_launch_ms_sustained"] = sustained["avg_launch_ms"]
     if prof and prof.get("avg_launch_us_kernel_trace"):
-        us = prof["avg_launch_us_kernel_trace"]          # ALL launches of the committed kernel trace, warm-up included
+        us = prof["avg_launch_us_kernel_trace"]          # the committed kernel trace's one-shot + warm-up + timed launches
         roof["frac_rocprof"] = round(n * BYTES_PER_SAMPLE / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
         roof["avg_launch_us_rocprof"] = us
+        if prof.get("sustained_avg_us"):                 # the committed trace's launches of the sustained leg
+            roof["frac_rocprof_sustained"] = round(n * BYTES_PER_SAMPLE / (prof["sustained_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
     result = {
         "metric": "Msamples/s IQ throughput + % HBM roofline, 1 GB i16 stream, 1/2/4/8 GPUs",
         "value": round(value, 1),
@@ -745,6 +750,15 @@ def main():
                 if rank == 0:
                     devices = [0] * world if share else list(range(world))
                     gather["product_ring"] = product_ring(devices)
+                    # the same ring with the gather BASELINE.json's north_star names (`doppler --gather rccl`): outputs of GPUs
+                    # 1..N-1 over RCCL into GPU 0, from there to the host.  Needs distinct devices (one communicator rank each).
+                    if len(set(devices)) == len(devices):
+                        try:
+                            gather["product_ring_rccl"] = product_ring(devices, gather="rccl")
+                        except Exception as e:
+                            gather["product_ring_rccl"] = {"error": str(e)[:300]}
+                    else:
+                        gather["product_ring_rccl"] = {"skipped": "the ranks share one GPU (development mode): RCCL needs one device per rank"}
                 barrier()
             except Exception as e:
                 if gather is None:

@@ -43,7 +43,7 @@ class StreamStats(C.Structure):
 
 
 class StreamOptions(C.Structure):
-    _fields_ = [("path", C.c_uint32), ("in_host_flags", C.c_uint32), ("out_host_flags", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("path", C.c_uint32), ("in_host_flags", C.c_uint32), ("out_host_flags", C.c_uint32), ("gather", C.c_uint32)]
 
 
 STREAM_PATHS = {"default": 0, "direct": 1, "staged": 2, "direct_in": 3, "direct_out": 4, "staged_per_slab": 5}
@@ -51,6 +51,9 @@ STREAM_COPY_ONLY = 0x100
 STREAM_UNPACED = 0x200
 STREAM_NO_PROBE = 0x400
 STREAM_SHARED_QUEUE = 0x800
+STREAM_DESCRIBE_RCCL = 0x1000
+STREAM_GATHER = {None: 0, "d2h": 0, "rccl": 1}
+STREAM_GATHER_SELF = 0x100
 
 
 class ResidentCounters(C.Structure):

@@ -67,6 +67,7 @@ const Flag kConstFlags[] = {
     {"SHIFT", "shift", 0, true, false, "frequency shift in Hz"},
     // extension of this build (the reference has no such flag): see args.h
     {"GPUS", "gpus", 0, false, false, "[extension] number of GPUs to spread the stream over (default 1, or $DOPPLER_GPUS)"},
+    {"GATHER", "gather", 0, false, false, "[extension] with --gpus N: how outputs reach the host: d2h = every GPU over its own PCIe link (default), rccl = over xGMI into the first GPU, from there"},
 };
 const Flag kTrackFlags[] = {
     {"SAMPLERATE", "samplerate", 's', true, false, "IQ data samplerate"},
@@ -81,6 +82,7 @@ const Flag kTrackFlags[] = {
     // extension of this build (the reference has no such flag): see args.h
     {"RANGERATEFILE", "range-rate-file", 0, false, false, "[extension] text file with one range rate (km/s) per whole second; replaces --tlefile/--tlename/--location"},
     {"GPUS", "gpus", 0, false, false, "[extension] number of GPUs to spread the stream over (default 1, or $DOPPLER_GPUS)"},
+    {"GATHER", "gather", 0, false, false, "[extension] with --gpus N: how outputs reach the host: d2h = every GPU over its own PCIe link (default), rccl = over xGMI into the first GPU, from there"},
 };
 
 void usage(FILE *f, const char *sub, const Flag *flags, size_t n)
@@ -190,6 +192,10 @@ int parse_args(int argc, char **argv, CommandArgs *out, bool *exit_now)
     };
     if (!parse_int<uint32_t>(val["SAMPLERATE"], &out->samplerate)) return bad("SAMPLERATE");
     if (val.count("GPUS") && (!parse_int<uint32_t>(val["GPUS"], &out->gpus) || out->gpus < 1 || out->gpus > 64)) return bad("GPUS");
+    if (val.count("GATHER")) {
+        if (val["GATHER"] == "rccl") out->gather_rccl = true;
+        else if (val["GATHER"] != "d2h") return bad("GATHER");
+    }
     out->inputtype = val["INTYPE"] == "f32" ? DataType::F32 : DataType::I16;
     out->outputtype = val.count("OUTTYPE") ? (val["OUTTYPE"] == "f32" ? DataType::F32 : DataType::I16) : out->inputtype;
     if (out->mode == Mode::Const) {

@@ -37,6 +37,9 @@ struct CommandArgs {                       // usage.rs:61-83
     std::string range_rate_file;
     // extension (not in the reference): GPUs to spread the stream over; 0 = not given (1, or $DOPPLER_GPUS)
     uint32_t gpus = 0;
+    // extension (not in the reference): --gather rccl: outputs of GPUs 1..N-1 over RCCL into the first GPU (the form
+    // BASELINE.json's north_star names); default: every GPU copies its own output to the host
+    bool gather_rccl = false;
 };
 
 // usage.rs:85-115 parse_location: "lat=58.64560,lon=23.15163,alt=8"

@@ -16,7 +16,8 @@
 //     offsets the sequential loop would have reached (a single read() stream is what bounded round 1 at 1.4 Gsamples/s);
 //   * a regular file on stdout: drained the same way with pwrite(); a pipe gets one ordered writer.
 // With --gpus N (extension) the ring spans N GPUs: slab k runs on GPU k mod N (dpx_stream_create_multi) — the slabs ARE
-// the time chunks of the sharded design, the counter is carried on the host, every GPU copies its own output back.
+// the time chunks of the sharded design, the counter is carried on the host, every GPU copies its own output back
+// (--gather rccl: the outputs of GPUs 1..N-1 go over RCCL into the first GPU and leave from there).
 // Live track mode (no --time) evaluates the orbit once per 8192-byte block, like the reference (main.rs:186-205): its
 // slabs are a single block.
 #include <errno.h>
@@ -473,8 +474,15 @@ int main(int argc, char **argv)
     const int n_slabs = slabs_per_gpu * (int)n_gpus;
 
     dpx_stream *stream = nullptr;
-    if (dpx_stream_create_multi(ctxs.data(), (int)ctxs.size(), in_fmt, out_fmt, args.samplerate, /*samplenr, main.rs:60*/ 0, slab_bytes,
-                                slabs_per_gpu, &stream) != DPX_OK) {
+    dpx_stream_options sopt = {};
+    bool gather_rccl = args.gather_rccl;
+    if (const char *e = getenv("DOPPLER_GATHER")) gather_rccl = gather_rccl || strcmp(e, "rccl") == 0;
+    sopt.gather = gather_rccl ? DPX_STREAM_GATHER_RCCL : DPX_STREAM_GATHER_D2H;
+    if (gather_rccl && getenv("DOPPLER_GATHER_SELF")) sopt.gather |= DPX_STREAM_GATHER_SELF;       // tests on a one-GPU box
+    if (const char *e = getenv("DPX_STREAM_PATH")) sopt.path = (uint32_t)atoi(e);
+    if (gather_rccl) info("\tgather          : RCCL into GPU %d", devices[0]);
+    if (dpx_stream_create_opts(ctxs.data(), (int)ctxs.size(), in_fmt, out_fmt, args.samplerate, /*samplenr, main.rs:60*/ 0, slab_bytes,
+                               slabs_per_gpu, &sopt, &stream) != DPX_OK) {
         fprintf(stderr, "doppler: %s\n", dpx_last_error());
         destroy_ctxs();
         return 1;

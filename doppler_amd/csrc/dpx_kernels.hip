@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(kBlock) void copy_kernel(const u32x4 *__restrict__ 
 // of spans written out once per group of 8 workgroups (2.6 MB for a 600 s replay).  The host uploads the spans themselves
 // (92 KB) and the index of every group (165 KB); this writes the rest on the device, 16 bytes per lane (round 6: the
 // 2.6 MB went over PCIe from pageable memory before, 240 of a plan's 840 us).
-__global__ __launch_bounds__(kBlock) void expand_walk_kernel(const u32x4 *__restrict__ spans, const uint32_t *__restrict__ index,
+__global__ __launch_bounds__(kBlock) void span_descriptors_kernel(const u32x4 *__restrict__ spans, const uint32_t *__restrict__ index,
                                                              u32x4 *__restrict__ desc, uint32_t n_desc)
 {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -1438,7 +1438,7 @@ int launch_expand_walk(const void *d_spans, const void *d_index, void *d_desc, u
 {
     static_assert(sizeof(WalkSeg) == 4 * sizeof(u32x4), "a descriptor is four 16-byte vectors");
     if (n_desc == 0) return DPX_OK;
-    expand_walk_kernel<<<(n_desc * 4u + kBlock - 1) / kBlock, kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+    span_descriptors_kernel<<<(n_desc * 4u + kBlock - 1) / kBlock, kBlock, 0, static_cast<hipStream_t>(stream)>>>(
         static_cast<const u32x4 *>(d_spans), static_cast<const uint32_t *>(d_index), static_cast<u32x4 *>(d_desc), n_desc);
     return hipGetLastError() == hipSuccess ? DPX_OK : DPX_ERR_HIP;
 }

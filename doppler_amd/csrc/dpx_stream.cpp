@@ -1,5 +1,6 @@
 // dpx_stream.cpp — the slab ring: streaming from host memory, on one GPU or several
 // (one of the translation units behind include/doppler_hip*.h: see dpx_internal.h)
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <sys/syscall.h>
@@ -64,6 +65,8 @@ struct dpx_stream_slab {
     char *h_in = nullptr, *h_out = nullptr;
     void *m_in = nullptr, *m_out = nullptr;   // the pinned buffers as the GPU addresses them (hipHostGetDevicePointer): the direct path's kernel arguments
     void *d_in = nullptr, *d_out = nullptr;   // HBM staging of the copy-engine path (allocated only for the sides that are staged)
+    void *g_out = nullptr;                    // RCCL gather: where the slab's output lands on the ring's first GPU (slabs of other GPUs only)
+    hipEvent_t ev_gather = nullptr;           // ... and when it has
     hipStream_t stream = nullptr;             // the slab's launches: its own stream where the kernel itself crosses PCIe (launches of several slabs
                                               // overlap) and on the per-slab form of the staged path; the GPU's `run` stream on the staged path
     bool owns_stream = false;
@@ -123,6 +126,20 @@ struct dpx_stream {
     };
     std::vector<std::unique_ptr<Lane>> lanes;     // one per context
     bool paced = true;                     // dpx_stream_options.path | DPX_STREAM_UNPACED: every D2H queued at submit time (A/B)
+    // dpx_stream_options.gather == DPX_STREAM_GATHER_RCCL (what BASELINE.json's north_star names: "RCCL over xGMI only for
+    // ordered gather back to stdout"): a slab of GPU g != 0 does not leave through g's own PCIe link; its output is sent
+    // over xGMI into a buffer on the ring's first GPU (one ncclSend / ncclRecv pair in one group, one communicator per GPU
+    // of this ONE process: ncclCommInitAll) and leaves from there, paced like that GPU's own slabs.  Input still goes to
+    // every GPU over its own link.  Every output byte then crosses GPU 0's link: the default (per-GPU D2H) is N times wider
+    // for a host consumer — README.md says so; this is the form the north_star asks for, behind the same ordering.
+    bool gather_rccl = false;
+    bool gather_self = false;              // DPX_STREAM_GATHER_SELF (tests on one GPU): GPU 0's own slabs go through a send/recv to itself
+    std::vector<void *> comms;             // ncclComm_t per context
+    hipStream_t gather_stream = nullptr;   // on GPU 0: the receives, in the order the groups were issued
+    std::mutex gather_mu;                  // one group at a time touches GPU 0's communicator (the enqueue threads of several GPUs)
+    uint64_t gathered_slabs = 0, gathered_bytes = 0;       // through ncclSend / ncclRecv so far (dpx_stream_describe)
+    bool gathered(size_t k) const { return gather_rccl && (k % ctxs.size() != 0 || gather_self); }
+    size_t down_lane(size_t k) const { return gathered(k) ? 0 : k % lanes.size(); }       // the GPU whose link a slab's output leaves through
     std::vector<dpx_stream_slab> slabs;
     size_t acq = 0;     // next slab to acquire            (producer side: acquire, then submit in the same order)
     size_t head = 0;    // oldest acquired slab, the next to submit
@@ -191,6 +208,49 @@ void prefer_numa_node(int node)
 #endif
 }
 
+// librccl, loaded when a ring asks for the RCCL gather (not a link-time dependency: a one-GPU user never needs it).
+// The handful of entry points used, with the signatures of rccl.h (ncclComm_t is an opaque pointer, ncclUint8 == 1).
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *buf, size_t count, int datatype, int peer, void *comm, hipStream_t stream) = nullptr;
+    int (*Recv)(void *buf, size_t count, int datatype, int peer, void *comm, hipStream_t stream) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+constexpr int kNcclUint8 = 1;
+
+const Rccl &rccl()
+{
+    static const Rccl r = [] {
+        Rccl x;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            x.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (x.lib) break;
+        }
+        if (!x.lib) return x;
+        x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(dlsym(x.lib, "ncclCommInitAll"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.lib, "ncclCommDestroy"));
+        x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(x.lib, "ncclGroupStart"));
+        x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(x.lib, "ncclGroupEnd"));
+        x.Send = reinterpret_cast<decltype(x.Send)>(dlsym(x.lib, "ncclSend"));
+        x.Recv = reinterpret_cast<decltype(x.Recv)>(dlsym(x.lib, "ncclRecv"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.lib, "ncclGetErrorString"));
+        x.ok = x.CommInitAll && x.CommDestroy && x.GroupStart && x.GroupEnd && x.Send && x.Recv && x.GetErrorString;
+        return x;
+    }();
+    return r;
+}
+
+#define DPX_NCCL(call)                                                                                     \
+    do {                                                                                                   \
+        const int rc_nccl_ = (call);                                                                       \
+        if (rc_nccl_ != 0) return dpx_api::fail(DPX_ERR_HIP, "%s failed: %s", #call, rccl().GetErrorString(rc_nccl_)); \
+    } while (0)
+
 }  // namespace
 
 extern "C" {
@@ -235,6 +295,30 @@ int dpx_stream_create_opts(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_
     s->slabs.resize((size_t)slabs_per_ctx * (size_t)n_ctx);
     for (int i = 0; i < n_ctx; ++i) s->lanes.emplace_back(new dpx_stream::Lane);
     s->paced = (o.path & DPX_STREAM_UNPACED) == 0;
+    if (!opt) if (const char *e = getenv("DPX_STREAM_GATHER")) o.gather = strcmp(e, "rccl") == 0 ? DPX_STREAM_GATHER_RCCL : (uint32_t)atoi(e);
+    if ((o.gather & 0xffu) > DPX_STREAM_GATHER_RCCL || (o.gather & ~(0xffu | DPX_STREAM_GATHER_SELF))) {
+        dpx_stream_destroy(s);
+        return fail(DPX_ERR_ARG, "unknown gather mode %u", o.gather);
+    }
+    s->gather_rccl = (o.gather & 0xffu) == DPX_STREAM_GATHER_RCCL;
+    s->gather_self = s->gather_rccl && (o.gather & DPX_STREAM_GATHER_SELF) != 0;
+    if (s->gather_rccl) {
+        if ((o.path & 0xffu) != DPX_STREAM_PATH_DEFAULT && (o.path & 0xffu) != DPX_STREAM_PATH_STAGED) {
+            dpx_stream_destroy(s);
+            return fail(DPX_ERR_ARG, "the RCCL gather runs on the staged path");
+        }
+        s->path = DPX_STREAM_PATH_STAGED;                 // outputs rest in HBM before they travel: whatever the slab size
+        for (int i = 0; i < n_ctx; ++i)
+            for (int j = 0; j < i; ++j)
+                if (ctxs[i]->device == ctxs[j]->device) {
+                    dpx_stream_destroy(s);
+                    return fail(DPX_ERR_ARG, "the RCCL gather needs distinct devices (device %d is listed twice): one communicator rank per GPU", ctxs[i]->device);
+                }
+        if (!rccl().ok) {
+            dpx_stream_destroy(s);
+            return fail(DPX_ERR_HIP, "librccl.so.1 could not be loaded (%s): the RCCL gather is unavailable, the default per-GPU D2H is not", dlerror() ? dlerror() : "symbols missing");
+        }
+    }
     for (size_t k = 0; k < s->slabs.size(); ++k) {
         dpx_stream_slab &b = s->slabs[k];
         b.ctx = ctxs[k % (size_t)n_ctx];                 // consecutive slabs on consecutive GPUs: their copies and kernels overlap
@@ -277,9 +361,35 @@ int dpx_stream_create_opts(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b.ev_up, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b.ev_run, hipEventDisableTiming);
+        if (e == hipSuccess && s->gathered(k)) {           // where this slab's output lands on the ring's first GPU
+            e = hipSetDevice(ctxs[0]->device);
+            if (e == hipSuccess) e = hipMalloc(&b.g_out, s->slab_out + 16);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&b.ev_gather, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipSetDevice(b.ctx->device);
+        }
         if (e != hipSuccess) {
             dpx_stream_destroy(s);
             return fail(DPX_ERR_HIP, "stream slab allocation failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (s->gather_rccl) {
+        std::vector<int> devs;
+        for (int i = 0; i < n_ctx; ++i) devs.push_back(ctxs[i]->device);
+        s->comms.assign((size_t)n_ctx, nullptr);
+        // RCCL greets on stdout when its first communicator is made ("RCCL version : ...", four lines) — and stdout is the
+        // sample stream of the `doppler` command.  File descriptor 1 points at stderr while the communicators are made.
+        fflush(stdout);
+        const int saved_out = dup(1);
+        if (saved_out >= 0) (void)dup2(2, 1);
+        const int rc = rccl().CommInitAll(s->comms.data(), n_ctx, devs.data());
+        fflush(stdout);
+        if (saved_out >= 0) { (void)dup2(saved_out, 1); close(saved_out); }
+        hipError_t e = hipSetDevice(ctxs[0]->device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->gather_stream, hipStreamNonBlocking);
+        if (rc != 0 || e != hipSuccess) {
+            const std::string why = rc != 0 ? rccl().GetErrorString(rc) : hipGetErrorString(e);
+            dpx_stream_destroy(s);
+            return fail(DPX_ERR_HIP, "RCCL gather: ncclCommInitAll over %d device(s) failed: %s", n_ctx, why.c_str());
         }
     }
     if (s->path == DPX_STREAM_PATH_STAGED && !(o.path & DPX_STREAM_NO_PROBE))
@@ -335,6 +445,8 @@ void dpx_stream_destroy(dpx_stream *s)
         if (b.done) (void)hipEventDestroy(b.done);
         if (b.ev_up) (void)hipEventDestroy(b.ev_up);
         if (b.ev_run) (void)hipEventDestroy(b.ev_run);
+        if (b.ev_gather) { (void)hipEventSynchronize(b.ev_gather); (void)hipEventDestroy(b.ev_gather); }
+        if (b.g_out) { (void)hipSetDevice(s->ctxs[0]->device); (void)hipFree(b.g_out); (void)hipSetDevice(b.ctx->device); }
         if (b.stream && b.owns_stream) (void)hipStreamDestroy(b.stream);
     }
     for (size_t i = 0; i < s->lanes.size(); ++i) {
@@ -344,6 +456,13 @@ void dpx_stream_destroy(dpx_stream *s)
         if (s->lanes[i]->run) { (void)hipStreamSynchronize(s->lanes[i]->run); (void)hipStreamDestroy(s->lanes[i]->run); }
         for (hipStream_t st : s->lanes[i]->parked) (void)hipStreamDestroy(st);
     }
+    if (s->gather_stream) {
+        (void)hipSetDevice(s->ctxs[0]->device);
+        (void)hipStreamSynchronize(s->gather_stream);
+        (void)hipStreamDestroy(s->gather_stream);
+    }
+    for (void *c : s->comms)
+        if (c) (void)rccl().CommDestroy(c);
     delete s;
 }
 
@@ -444,8 +563,9 @@ int pump_down(dpx_stream *s, dpx_stream::Lane &lane, long upto)
             for (size_t q : lane.down_q) forced = forced || q == (size_t)upto;
         if (!forced && lane.last_down >= 0 && hipEventQuery(s->slabs[(size_t)lane.last_down].done) != hipSuccess) break;
         dpx_stream_slab &b = s->slabs[k];
-        DPX_HIP(hipStreamWaitEvent(lane.down, b.ev_run, 0));
-        DPX_HIP(hipMemcpyAsync(b.h_out, b.d_out, b.out_bytes, hipMemcpyDeviceToHost, lane.down));
+        const bool via_gpu0 = s->gathered(k);                      // its output was sent to the ring's first GPU (RCCL gather)
+        DPX_HIP(hipStreamWaitEvent(lane.down, via_gpu0 ? b.ev_gather : b.ev_run, 0));
+        DPX_HIP(hipMemcpyAsync(b.h_out, via_gpu0 ? b.g_out : b.d_out, b.out_bytes, hipMemcpyDeviceToHost, lane.down));
         DPX_HIP(hipEventRecord(b.done, lane.down));
         lane.last_down = (long)k;
         lane.down_q.pop_front();
@@ -493,12 +613,35 @@ int enqueue_slab(dpx_stream *s, dpx_stream_slab &b, double *upload_us, double *e
     if (!s->out_direct()) {
         if (st_down != b.stream) {
             DPX_HIP(hipEventRecord(b.ev_run, b.stream));
-            {
-                std::lock_guard<std::mutex> lk(lane.mu);
-                lane.down_q.push_back(k_slab);
+            if (s->gathered(k_slab)) {
+                // RCCL ordered gather: this GPU sends, the ring's first GPU receives — one group, so that the pair is
+                // issued together whichever thread gets here first; the D2H then queues on GPU 0's `down` stream and is
+                // handed to the runtime by dpx_stream_next / that GPU's own submits (paced like its own slabs)
+                const Rccl &nc = rccl();
+                const size_t g = k_slab % s->lanes.size();
+                std::lock_guard<std::mutex> glk(s->gather_mu);
+                DPX_NCCL(nc.GroupStart());
+                int e1 = nc.Send(b.d_out, b.out_bytes, kNcclUint8, 0, s->comms[g], b.stream);
+                (void)hipSetDevice(s->ctxs[0]->device);
+                int e2 = nc.Recv(b.g_out, b.out_bytes, kNcclUint8, (int)g, s->comms[0], g == 0 ? b.stream : s->gather_stream);
+                const int e3 = nc.GroupEnd();
+                hipError_t he = hipEventRecord(b.ev_gather, g == 0 ? b.stream : s->gather_stream);
+                (void)hipSetDevice(b.ctx->device);
+                if (e1 || e2 || e3) return fail(DPX_ERR_HIP, "RCCL gather of a slab failed: %s", nc.GetErrorString(e1 ? e1 : e2 ? e2 : e3));
+                if (he != hipSuccess) return fail(DPX_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(he));
+                ++s->gathered_slabs;
+                s->gathered_bytes += b.out_bytes;
+                dpx_stream::Lane &l0 = *s->lanes[0];
+                std::lock_guard<std::mutex> lk(l0.mu);
+                l0.down_q.push_back(k_slab);
+            } else {
+                {
+                    std::lock_guard<std::mutex> lk(lane.mu);
+                    lane.down_q.push_back(k_slab);
+                }
+                rc = pump_down(s, lane, s->paced ? -1 : (long)k_slab);
+                if (rc != DPX_OK) return rc;
             }
-            rc = pump_down(s, lane, s->paced ? -1 : (long)k_slab);
-            if (rc != DPX_OK) return rc;
         } else {
             DPX_HIP(hipMemcpyAsync(b.h_out, b.d_out, b.out_bytes, hipMemcpyDeviceToHost, st_down));
             DPX_HIP(hipEventRecord(b.done, st_down));
@@ -661,15 +804,16 @@ int dpx_stream_next(dpx_stream *s, const void **pinned_out, size_t *out_bytes)
         DPX_HIP(hipSetDevice(b.ctx->device));
     }
     const bool staged_out = !s->out_direct() && !s->per_slab();
+    const size_t dl = s->down_lane(s->tail);         // the GPU whose link this output leaves through (RCCL gather: the first)
     if (staged_out) {                      // the slab's D2H may still be queued behind its GPU's previous one (which is done: it was handed out)
-        DPX_ENTER(b.ctx);
-        const int rc = pump_down(s, *s->lanes[s->tail % s->lanes.size()], (long)s->tail);
+        DPX_ENTER(s->ctxs[dl]);
+        const int rc = pump_down(s, *s->lanes[dl], (long)s->tail);
         if (rc != DPX_OK) return rc;
     }
     DPX_HIP(hipEventSynchronize(b.done));
     if (staged_out) {                      // ... and the next one of this GPU can go now
-        DPX_ENTER(b.ctx);
-        const int rc = pump_down(s, *s->lanes[s->tail % s->lanes.size()], -1);
+        DPX_ENTER(s->ctxs[dl]);
+        const int rc = pump_down(s, *s->lanes[dl], -1);
         if (rc != DPX_OK) return rc;
     }
     b.state = 3;
@@ -706,7 +850,7 @@ int dpx_stream_describe(const dpx_stream *s, uint32_t *path, int *numa_nodes, si
         int probes = 0;
         bool shared = false;
         for (const auto &ln : s->lanes) { probes = std::max(probes, ln->probes); shared = shared || ln->shared_queue; }
-        *path |= ((uint32_t)probes & 0xfu) << 16 | (shared ? DPX_STREAM_SHARED_QUEUE : 0u);
+        *path |= ((uint32_t)probes & 0xfu) << 16 | (shared ? DPX_STREAM_SHARED_QUEUE : 0u) | (s->gather_rccl ? DPX_STREAM_DESCRIBE_RCCL : 0u);
     }
     if (n_slabs) *n_slabs = s->slabs.size();
     for (size_t k = 0; numa_nodes && k < cap && k < s->slabs.size(); ++k) numa_nodes[k] = s->slabs[k].numa_node;

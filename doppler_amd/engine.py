@@ -191,21 +191,23 @@ class Stream:
     the outputs in order.  The sample counter is carried from slab to slab like `samplenr` (main.rs:60)."""
 
     def __init__(self, ctx, in_fmt, out_fmt, samplerate, samplenum=0, slab_bytes=8 << 20, n_slabs=3, path=None,
-                 copy_only=False, in_host_flags=0, out_host_flags=0, unpaced=False, no_probe=False):
+                 copy_only=False, in_host_flags=0, out_host_flags=0, unpaced=False, no_probe=False, gather=None, gather_self=False):
         """ctx: one Context, or a list of Contexts (one per GPU; slab k runs on context k mod len(ctx), n_slabs slabs
-        per context).  path / copy_only / *_host_flags: dpx_stream_options (measurement only; None = the library's default)."""
+        per context).  path / copy_only / *_host_flags: dpx_stream_options (measurement only; None = the library's default).
+        gather="rccl": outputs of GPUs 1..N-1 travel over RCCL into the first GPU and leave from there (distinct devices only)."""
         self._lib = _lib_handle()
         self.ctxs = list(ctx) if isinstance(ctx, (list, tuple)) else [ctx]
         self.ctx = self.ctxs[0]
         self.in_fmt, self.out_fmt = fmt_code(in_fmt), fmt_code(out_fmt)
         self._h = C.c_void_p()
         arr = (C.c_void_p * len(self.ctxs))(*[c.handle.value for c in self.ctxs])
-        if path is None and not copy_only and not in_host_flags and not out_host_flags and not unpaced and not no_probe:
+        if path is None and not copy_only and not in_host_flags and not out_host_flags and not unpaced and not no_probe and not gather:
             check(self._lib.dpx_stream_create_multi(arr, len(self.ctxs), self.in_fmt, self.out_fmt, int(samplerate),
                                                     int(samplenum), int(slab_bytes), int(n_slabs), C.byref(self._h)))
         else:
             opt = _lib.StreamOptions(_lib.STREAM_PATHS[path or "default"] | (_lib.STREAM_COPY_ONLY if copy_only else 0) | (_lib.STREAM_UNPACED if unpaced else 0) | (_lib.STREAM_NO_PROBE if no_probe else 0),
-                                     int(in_host_flags), int(out_host_flags), 0)
+                                     int(in_host_flags), int(out_host_flags),
+                                     _lib.STREAM_GATHER[gather] | (_lib.STREAM_GATHER_SELF if gather_self else 0))
             check(self._lib.dpx_stream_create_opts(arr, len(self.ctxs), self.in_fmt, self.out_fmt, int(samplerate),
                                                    int(samplenum), int(slab_bytes), int(n_slabs), C.byref(opt), C.byref(self._h)))
 
@@ -218,7 +220,8 @@ class Stream:
         names = {v: k for k, v in _lib.STREAM_PATHS.items()}
         return {"path": names[path.value & 0xff], "copy_only": bool(path.value & _lib.STREAM_COPY_ONLY),
                 "unpaced": bool(path.value & _lib.STREAM_UNPACED), "probe_rounds": (path.value >> 16) & 0xf,
-                "streams_share_a_queue": bool(path.value & _lib.STREAM_SHARED_QUEUE), "numa_nodes": list(nodes[: n.value])}
+                "streams_share_a_queue": bool(path.value & _lib.STREAM_SHARED_QUEUE),
+                "gather": "rccl" if path.value & _lib.STREAM_DESCRIBE_RCCL else "d2h", "numa_nodes": list(nodes[: n.value])}
 
     def next_view(self):
         """Waits for the oldest submitted slab; returns a VIEW of its pinned output (valid until release())."""

@@ -141,10 +141,22 @@ int dpx_stream_get_stats(const dpx_stream *s, dpx_stream_stats *out);
 #define DPX_STREAM_UNPACED 0x200u
 #define DPX_STREAM_NO_PROBE 0x400u        /* STAGED: take the three streams of a GPU as the runtime deals them (A/B) */
 #define DPX_STREAM_SHARED_QUEUE 0x800u    /* dpx_stream_describe only: after the last probe round two of a GPU's streams still shared a hardware queue */
+#define DPX_STREAM_DESCRIBE_RCCL 0x1000u  /* dpx_stream_describe only: the ring gathers through RCCL */
+/* gather — how the outputs of a ring over several GPUs reach the host:
+ *   DPX_STREAM_GATHER_D2H   every GPU copies its own slabs to their pinned output buffers over its own PCIe link   [the default]
+ *   DPX_STREAM_GATHER_RCCL  BASELINE.json's north_star form: the slabs of GPUs 1..N-1 go over xGMI into the first GPU
+ *                           (one ncclSend / ncclRecv pair per slab, single-process communicators from ncclCommInitAll;
+ *                           librccl is loaded on demand) and leave from there — every output byte through ONE PCIe link.
+ *                           Needs distinct devices; runs on the staged path.  `doppler --gather rccl`, or DPX_STREAM_GATHER=rccl
+ *                           in the environment for rings created without options.
+ *   | DPX_STREAM_GATHER_SELF  (tests on a one-GPU box) the first GPU's own slabs take the same road: a send / recv to itself */
+#define DPX_STREAM_GATHER_D2H 0u
+#define DPX_STREAM_GATHER_RCCL 1u
+#define DPX_STREAM_GATHER_SELF 0x100u
 typedef struct dpx_stream_options {
     uint32_t path;
     uint32_t in_host_flags, out_host_flags;
-    uint32_t reserved;
+    uint32_t gather;
 } dpx_stream_options;
 int dpx_stream_create_opts(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_fmt, uint32_t samplerate,
                            uint32_t samplenum0, size_t slab_bytes, int slabs_per_ctx, const dpx_stream_options *opt,

@@ -202,6 +202,28 @@ def test_files_in_and_out_and_several_gpus(orc, gpus):
     assert_same_bytes(got, want, "i16", "complete blocks only (files)")
 
 
+def test_gather_rccl_flag_of_the_command(orc):
+    """`doppler const --gather rccl` (extension; the north_star's "RCCL over xGMI only for ordered gather back to stdout"): on
+    this one-GPU box every slab takes an ncclSend / ncclRecv to the GPU itself (DOPPLER_GATHER_SELF) before it leaves — files
+    and pipes, the same bytes as the oracle; two contexts on one device are refused with the library's message; an unknown
+    value is a usage error."""
+    rate = 1024000
+    x = make_iq("i16", 2048 * 700 + 5, 321, full_scale=True)[: 8192 * 700]
+    want, _ = orc.const_stream(x, "i16", "i16", 5001, rate, threads=4)
+    args = ["const", "-s", str(rate), "-i", "i16", "--shift", "5001", "--gather", "rccl"]
+    for slab in ("65536", "4194304"):
+        r, got = run_cli_files(args, x, dict(DOPPLER_GATHER_SELF="1", DOPPLER_SLAB_BYTES=slab))
+        assert r.returncode == 0 and b"RCCL into GPU 0" in r.stderr, r.stderr[-800:]
+        assert_same_bytes(got, want, "i16", "--gather rccl, files, slab %s" % slab)
+    r = run_cli(args, x, dict(DOPPLER_GATHER_SELF="1"))
+    assert r.returncode == 0, r.stderr[-800:]
+    assert_same_bytes(np.frombuffer(r.stdout, dtype=np.uint8), want, "i16", "--gather rccl, pipes")
+    r = run_cli(args + ["--gpus", "2"], x, dict(DOPPLER_DEVICES="0,0"))
+    assert r.returncode != 0 and b"distinct devices" in r.stderr, r.stderr[-800:]
+    r = run_cli(["const", "-s", str(rate), "-i", "i16", "--shift", "5001", "--gather", "nvlink"], x)
+    assert r.returncode != 0 and b"isn't a valid value" in r.stderr
+
+
 def test_track_replay_over_two_gpus_with_files(orc):
     """Track replay with the slabs of one stream alternating between two contexts: the per-block schedule and the carried
     counter live on the host, so the output is the single-GPU one."""

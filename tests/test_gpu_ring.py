@@ -157,3 +157,44 @@ def test_copy_only_calibration_moves_the_bytes_it_claims(ctx, path):
             assert np.array_equal(got, x)
     finally:
         st.close()
+
+
+def test_rccl_gather_on_one_gpu_sends_to_itself(ctx, orc):
+    """gather="rccl" (BASELINE.json's north_star form: outputs over RCCL into the first GPU, from there to the host) on the one
+    GPU a test box has: ncclCommInitAll over one device, every slab through an ncclSend / ncclRecv pair to itself
+    (DPX_STREAM_GATHER_SELF), then the paced D2H — the machinery a ring over N GPUs runs per slab, never executed between
+    two physical devices here (README.md says so).  Bytes against the oracle; a device listed twice is refused."""
+    import doppler_amd
+    rate = 1024000
+    slab_bytes, n_ring = 1 << 20, 3
+    per = slab_bytes // 4
+    sizes = [per, per, per - 40, per, 7, per, per, per // 3, per, per]
+    x = make_iq("i16", sum(sizes), 2024, full_scale=True)
+    segs = [(m, float(np.float32(5001.0 + 3.0 * i))) for i, m in enumerate(sizes)]
+    st = doppler_amd.Stream(ctx, "i16", "f32", rate, slab_bytes=slab_bytes, n_slabs=n_ring, gather="rccl", gather_self=True)
+    try:
+        d = st.describe()
+        assert d["gather"] == "rccl" and d["path"] == "staged", d
+        got = drive(st, x, 4, [(m, [sg]) for m, sg in zip(sizes, segs)], n_ring)
+        want, sn = orc.segments_stream(x, "i16", "f32", segs, rate, threads=8)
+        assert st.samplenum == sn
+        assert_same_bytes(got, want, "f32", "RCCL gather, self send/recv")
+    finally:
+        st.close()
+    # without the self flag a one-GPU ring has nothing to gather: the communicator is made, no slab travels
+    st = doppler_amd.Stream(ctx, "i16", "i16", rate, slab_bytes=slab_bytes, n_slabs=2, gather="rccl")
+    try:
+        got = drive(st, x[: 3 * slab_bytes], 4, [(per, [(per, 5000.0)])] * 3, 2)
+        want, _ = orc.segments_stream(x[: 3 * slab_bytes], "i16", "i16", [(3 * per, 5000.0)], rate, threads=8)
+        assert_same_bytes(got, want, "i16", "RCCL gather over one GPU")
+    finally:
+        st.close()
+    other = doppler_amd.Context(0)
+    try:
+        with pytest.raises(doppler_amd.DspError) as e:
+            doppler_amd.Stream([ctx, other], "i16", "i16", rate, slab_bytes=slab_bytes, n_slabs=2, gather="rccl")
+        assert "distinct devices" in str(e.value)
+        with pytest.raises(doppler_amd.DspError):
+            doppler_amd.Stream(ctx, "i16", "i16", rate, slab_bytes=slab_bytes, n_slabs=2, gather="rccl", path="direct")
+    finally:
+        other.close()

@@ -3,6 +3,8 @@
 # command (headline and track workloads), plus a calibration pass on the plain copy kernel; the summaries
 # (gpurun_out/<round>_*.md / .json, small) are what comes back — copy them into profiles/.
 #   tools/profile_round.sh r05
+# The headline's kernel trace is the driver's own command shape (--steps 20 --warmup 5, sustained leg included): the summary quotes
+# the first 1 + W + K launches (one-shot, warm-up, timed region: what `roofline.frac` times) and the sustained launches apart.
 # The track workload is profiled over 300 launches (bench.py's own default for `--workload track`): the clocks need
 # 50-150 ms under load to settle, and the summary quotes the launches after the first 160 ms ("settled") beside the
 # average over all of them, so that it can be compared with the settled figure `extra.track` carries in the bench line.
@@ -17,7 +19,7 @@ for wl in const track track_256k config4_chunk; do
   STEPS=20; [ $wl != const ] && STEPS=300
   CMD="python $REPO/bench.py --workload $wl --steps $STEPS --warmup 5 --no-cpu --no-extra"
   rocprofv3 --kernel-trace --stats -d $OUT/${wl}_trace -o bench -- $CMD > $OUT/${wl}_trace.log 2>&1
-  CMD="python $REPO/bench.py --workload $wl --steps 20 --warmup 5 --no-cpu --no-extra"
+  CMD="python $REPO/bench.py --workload $wl --steps 20 --warmup 5 --no-cpu --no-extra --no-sustain"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${wl}_fetch -o bench -- $CMD > $OUT/${wl}_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${wl}_write -o bench -- $CMD > $OUT/${wl}_write.log 2>&1
 done

@@ -45,6 +45,16 @@ def settled(db_path, pattern, after_ms=160.0):
     return len(d), sum(d) / len(d), d[len(d) // 2]
 
 
+def head_and_rest(db_path, pattern, n_head):
+    """the kernel's launches in start order: (count, avg us) of the first n_head, and (count, avg us, median us) of the rest"""
+    db = sqlite3.connect(db_path)
+    d = [r[0] / 1e3 for r in db.execute("select duration from kernels where name like ? order by start", ("%" + pattern + "%",)).fetchall()]
+    head, rest = d[:n_head], sorted(d[n_head:])
+    if not head:
+        return None
+    return (len(head), sum(head) / len(head)), ((len(rest), sum(rest) / len(rest), rest[len(rest) // 2]) if len(rest) >= 5 else None)
+
+
 def counter(db_path, name, agg="avg"):
     """per kernel: (launches, avg value) — or the largest value (calibration: the context's 16-byte warm-up launch of the
     copy kernel must not be averaged with the 1 GiB copies)"""
@@ -96,7 +106,18 @@ def main():
             r["launches"] = c
             lines += ["", "Dominant kernel `%s`: average %.3f us over %d launches (warm-up included) -> %.1f GB/s algorithmic "
                       "(%d B per launch) = %.1f %% of the 8.0 TB/s HBM3E peak." % (n, a, c, alg / a / 1e3, alg, alg / a / 1e3 / 80.0)]
-            st = settled(db_of(os.path.join(src, wl + "_trace")), pat)
+            if wl == "const":
+                # the driver's command: 1 one-shot + 5 warm-up + 20 timed launches, then the sustained leg (bench.py, SUSTAIN_S)
+                hr = head_and_rest(db_of(os.path.join(src, wl + "_trace")), pat, 26)
+                if hr and hr[1]:
+                    (hn, ha), (rn, ra, rm) = hr
+                    r["avg_launch_us_kernel_trace"] = round(ha, 3)
+                    r["launches"] = hn
+                    r["sustained_launches"], r["sustained_avg_us"], r["sustained_median_us"] = rn, round(ra, 3), round(rm, 3)
+                    lines += ["Of these, the first %d (one-shot, warm-up, the K timed launches: what `roofline.frac` times): average %.3f us -> %.1f %%; "
+                              "the %d launches of the sustained leg (`roofline.frac_sustained`): average %.3f us, median %.3f us -> %.1f %% / %.1f %%." %
+                              (hn, ha, alg / ha / 1e3 / 80.0, rn, ra, rm, alg / ra / 1e3 / 80.0, alg / rm / 1e3 / 80.0)]
+            st = settled(db_of(os.path.join(src, wl + "_trace")), pat) if wl != "const" else None
             if st:
                 st = (st[0] // pieces, st[1] * pieces, st[2] * pieces)
                 # avg_launch_us_kernel_trace stays the average over ALL launches (bench.py: frac_rocprof); the settled subset
