@@ -741,29 +741,44 @@ def main():
         # process feeding every GPU's slab ring from pinned memory, per-GPU D2H, outputs in order.  The other ranks free
         # their buffers and wait at the barrier while rank 0 opens a context on every device and runs that ring.
         if world > 1 or os.environ.get("DPX_BENCH_FORCE_PRODUCT_RING") == "1":
+            if gather is None:
+                gather = {}
+            if rank != 0:
+                del x, out
+                x = out = None
+                torch.cuda.empty_cache()
+            barrier()
+            # The other ranks wait on the process group's STORE (host side), not in a collective: a barrier kernel spinning on
+            # GPUs 1..N-1 would sit beside the ring's launches there.  Rank 0 always reaches the key, whatever the ring did.
+            store = None
             try:
-                if rank != 0:
-                    del x, out
-                    x = out = None
-                    torch.cuda.empty_cache()
-                barrier()
-                if rank == 0:
-                    devices = [0] * world if share else list(range(world))
+                store = dist.distributed_c10d._get_default_store()
+            except Exception:
+                store = None
+            if rank == 0:
+                devices = [0] * world if share else list(range(world))
+                try:
                     gather["product_ring"] = product_ring(devices)
-                    # the same ring with the gather BASELINE.json's north_star names (`doppler --gather rccl`): outputs of GPUs
-                    # 1..N-1 over RCCL into GPU 0, from there to the host.  Needs distinct devices (one communicator rank each).
-                    if len(set(devices)) == len(devices):
-                        try:
-                            gather["product_ring_rccl"] = product_ring(devices, gather="rccl")
-                        except Exception as e:
-                            gather["product_ring_rccl"] = {"error": str(e)[:300]}
-                    else:
-                        gather["product_ring_rccl"] = {"skipped": "the ranks share one GPU (development mode): RCCL needs one device per rank"}
-                barrier()
-            except Exception as e:
-                if gather is None:
-                    gather = {}
-                gather["product_ring"] = {"error": str(e)[:300]}
+                except Exception as e:
+                    gather["product_ring"] = {"error": str(e)[:300]}
+                # the same ring with the gather BASELINE.json's north_star names (`doppler --gather rccl`): outputs of GPUs
+                # 1..N-1 over RCCL into GPU 0, from there to the host.  Needs distinct devices (one communicator rank each).
+                if len(set(devices)) == len(devices):
+                    try:
+                        gather["product_ring_rccl"] = product_ring(devices, gather="rccl")
+                    except Exception as e:
+                        gather["product_ring_rccl"] = {"error": str(e)[:300]}
+                else:
+                    gather["product_ring_rccl"] = {"skipped": "the ranks share one GPU (development mode): RCCL needs one device per rank"}
+                if store is not None:
+                    store.set("dpx_product_ring_done", "1")
+            elif store is not None:
+                import datetime
+                try:
+                    store.wait(["dpx_product_ring_done"], datetime.timedelta(seconds=GATHER_TIMEOUT_S))
+                except Exception:
+                    pass
+            barrier()
         gather_state["done"] = True
         timer.cancel()
         LEGS["gather"] = round(time.perf_counter() - t_leg, 3)

@@ -316,7 +316,7 @@ int dpx_stream_create_opts(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_
                 }
         if (!rccl().ok) {
             dpx_stream_destroy(s);
-            return fail(DPX_ERR_HIP, "librccl.so.1 could not be loaded (%s): the RCCL gather is unavailable, the default per-GPU D2H is not", dlerror() ? dlerror() : "symbols missing");
+            return fail(DPX_ERR_HIP, "librccl.so.1 could not be loaded or lacks an entry point: the RCCL gather is unavailable, the default per-GPU D2H is not");
         }
     }
     for (size_t k = 0; k < s->slabs.size(); ++k) {
@@ -346,9 +346,9 @@ int dpx_stream_create_opts(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_
             // The first slab of every context makes its GPU's streams, one after the other: the runtime deals streams out
             // over a handful of hardware queues (4 by default), and two ACTIVE streams on one hardware queue wait for each
             // other's copies — `up` and `down` on one queue is H2D and D2H taking turns (28 GB/s each way; seen in a process
-            // that already held streams: bench.py with torch, GPU_MAX_HW_QUEUES=4 against 16).  Three streams created
-            // back to back land on different queues; a stream per slab on top of them (rounds 2-5, and this round's first
-            // form of the staged path) did not.
+            // that already held streams: bench.py with torch, GPU_MAX_HW_QUEUES=4 against 16).  Which queue a stream gets
+            // is the runtime's business (three streams created back to back shared one in a bare process, a stream per
+            // slab on top of `up` / `down` did inside bench.py): separate_lane_streams() below measures and replaces.
             dpx_stream::Lane &ln = *s->lanes[k];
             e = hipStreamCreateWithFlags(&ln.up, hipStreamNonBlocking);
             if (e == hipSuccess && s->path == DPX_STREAM_PATH_STAGED) e = hipStreamCreateWithFlags(&ln.run, hipStreamNonBlocking);
@@ -358,14 +358,18 @@ int dpx_stream_create_opts(dpx_ctx *const *ctxs, int n_ctx, int in_fmt, int out_
             if (s->path == DPX_STREAM_PATH_STAGED) b.stream = s->lanes[k % (size_t)n_ctx]->run;
             else { e = hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking); b.owns_stream = e == hipSuccess; }
         }
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b.ev_up, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b.ev_run, hipEventDisableTiming);
+        // an event belongs to the device it is recorded on: `done` is recorded where the slab's output leaves — its own GPU,
+        // or the ring's first GPU when the output is gathered there
         if (e == hipSuccess && s->gathered(k)) {           // where this slab's output lands on the ring's first GPU
             e = hipSetDevice(ctxs[0]->device);
             if (e == hipSuccess) e = hipMalloc(&b.g_out, s->slab_out + 16);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&b.ev_gather, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming);
             if (e == hipSuccess) e = hipSetDevice(b.ctx->device);
+        } else if (e == hipSuccess) {
+            e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming);
         }
         if (e != hipSuccess) {
             dpx_stream_destroy(s);
@@ -486,10 +490,10 @@ namespace {
 // hardware queues (GPU_MAX_HW_QUEUES, 4 by default) by rules of its own, and what queues behind a copy in one stream — the
 // event record that releases the next stage — holds up every other stream on that queue: `up` and `down` on one queue is
 // H2D and D2H taking turns at the link (28 GB/s each way instead of 47: measured with the streams created back to back in
-// a fresh process, and with a stream per slab inside bench.py).  So the ring measures once, when it is created: two copies
-// each way on `up` and `down`, alone and together (sharing shows as the sum instead of the maximum), and a 16-byte launch
-// on `run` against each (sharing shows as the launch waiting for the copies).  A stream that shares is parked — kept, idle,
-// so that its replacement is dealt another queue — and replaced; at most eight rounds, ~2 ms each; the outcome is in
+// a fresh process, and with a stream per slab inside bench.py).  So the ring measures once, when it is created: one stream
+// is given two copies, another a 16-byte launch — on a queue of its own the launch is back in ~20 us, on a shared one only
+// after the copies (`up` against `down`, `down` against `up`, each against `run`).  A stream that shares is parked — kept,
+// idle, so that its replacement is dealt another queue — and replaced; at most eight rounds, ~2 ms each; the outcome is in
 // dpx_stream_describe.  Performance only: a ring whose streams still share is slow, never wrong.
 void separate_lane_streams(dpx_stream *s, size_t lane_index)
 {
@@ -503,7 +507,10 @@ void separate_lane_streams(dpx_stream *s, size_t lane_index)
     auto secs = [](clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); };
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     for (hipEvent_t &e : ev)
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            for (hipEvent_t made : ev) if (made) (void)hipEventDestroy(made);
+            return;
+        }
     auto up2 = [&] { for (int i = 0; i < 2; ++i) { (void)hipMemcpyAsync(b.d_in, b.h_in, nb, hipMemcpyHostToDevice, ln.up); (void)hipEventRecord(ev[0], ln.up); } };
     auto down2 = [&] { for (int i = 0; i < 2; ++i) { (void)hipMemcpyAsync(b.h_out, b.d_out, nb, hipMemcpyDeviceToHost, ln.down); (void)hipEventRecord(ev[1], ln.down); } };
     auto run1 = [&] { (void)dpx::launch_copy(b.d_in, static_cast<char *>(b.d_in) + 64, 16, ln.run); (void)hipEventRecord(ev[2], ln.run); };
@@ -517,7 +524,7 @@ void separate_lane_streams(dpx_stream *s, size_t lane_index)
     // how long a 16-byte launch on `probe` takes to come back while `busy` holds two copies: ~20 us on a queue of its own,
     // the copies' ~600 us behind them
     auto tiny = [&](hipStream_t st) { (void)dpx::launch_copy(b.d_in, static_cast<char *>(b.d_in) + 64, 16, st); (void)hipEventRecord(ev[2], st); };
-    auto held_up = [&](bool busy_is_up, hipStream_t busy, hipStream_t probe) {
+    auto held_up_once = [&](bool busy_is_up, hipStream_t busy, hipStream_t probe) {
         const clk::time_point t = clk::now();
         if (busy_is_up) up2(); else down2();
         tiny(probe);
@@ -527,6 +534,10 @@ void separate_lane_streams(dpx_stream *s, size_t lane_index)
         const double t_busy = secs(t);
         (void)hipStreamSynchronize(probe);
         return t_probe > 0.5 * t_busy;
+    };
+    // (a late wake-up of this thread on a loaded host looks like a held-up launch: a positive has to repeat)
+    auto held_up = [&](bool busy_is_up, hipStream_t busy, hipStream_t probe) {
+        return held_up_once(busy_is_up, busy, probe) && held_up_once(busy_is_up, busy, probe);
     };
     const bool debug = getenv("DPX_STREAM_DEBUG") != nullptr;
     up2(); down2(); run1(); tiny(ln.up); tiny(ln.down);          // first use of the three streams, untimed
