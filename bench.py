@@ -115,7 +115,7 @@ REPLAYS = {
                       "doppler track -s 1024000 -i f32 -o i16, 1 h replay: rank 3 of 8's time chunk (460.8 M samples, counter seeded from "
                       "the closed form): one GPU's share of BASELINE.json configs[4]"),
 }
-SUSTAIN_S = 2.5      # headline: seconds of back-to-back launches after the timed region (roofline.frac_sustained)
+SUSTAIN_S = 5.5      # headline: seconds of back-to-back launches after the timed region (roofline.frac_sustained): longer than the 5 s period of the driver's gpu_busy sampler
 SETTLE_S = 0.15     # untimed launches before the settled measurement of a secondary workload (clocks: profiles/r02_walk.md)
 
 
