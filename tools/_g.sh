@@ -1,30 +1,16 @@
-set -u
-EXE=doppler_amd/bin/doppler
-F=/dev/shm/dpx_in.iq
-python - <<PY
-import numpy as np
-rng = np.random.default_rng(1)
-rng.integers(-23170, 23171, size=1 << 31, dtype=np.int16).tofile("$F")     # 4 GiB
+mkdir -p gpurun_out/r06
+bash tools/profile_round.sh r06 > gpurun_out/r06_profile_round.log 2>&1
+tail -3 gpurun_out/r06_profile_round.log
+cp gpurun_out/r06_pmc_traffic.json profiles/r06_pmc_traffic.json
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r06_bench_line.json 2> gpurun_out/r06/bench_final.err
+python - <<'PY'
+import json
+l=json.loads(open("gpurun_out/r06_bench_line.json").read().strip().splitlines()[-1])
+r=l['extra']['stream_ring']
+print(l['value'], l['ms_per_step'], {k:l['roofline'].get(k) for k in ('frac','frac_sustained','sustained_s','sustained_launches','frac_rocprof','frac_rocprof_sustained','traffic')})
+print('ring', r['Msamples_per_s'], r['roofline']['achieved'], r['roofline']['peak'], r['roofline']['frac'], r['roofline']['copy_only_ring_GB_per_s'], r['GB_per_s_in_50ms_windows'], r['stream_probe_rounds'], r['roofline']['link'])
+for k in ("track","track_256k","config4_chunk"):
+    e=l["extra"][k]; print(' ', k, e["roofline"]["frac"], e["roofline"]["frac_settled"], e["roofline"].get("frac_rocprof"), e["roofline"].get("frac_rocprof_settled"), e["config"]["plan_ms"], e["config"]["one_shot_ms"], e["config"]["plan_parts_us"])
+print('cpu', l['cpu_baseline']['value'], l['cpu_baseline']['all_cores'], l['cpu_baseline']['gpu_output_bit_exact_on_sample'], l['legs_s'])
 PY
-run() {
-  local label=$1; local out=$2; shift; shift
-  s=$(date +%s.%N)
-  env DOPPLER_STATS=1 "$@" $EXE const -s 1024000 -i i16 --shift 5000 < $F 2>/tmp/dpx_err > $out
-  e=$(date +%s.%N)
-  st=$(grep "doppler stats: [0-9]" /tmp/dpx_err | sed 's/.*= \([0-9.]*\) Msamples.*/\1/')
-  how=$(grep "doppler stats: [0-9]" /tmp/dpx_err | sed 's/.*slabs of/slabs of/')
-  python -c "t=$e-$s; print('%-50s steady %8s Msamples/s   whole %.3f s  %s' % ('$label', '$st', t, '''$how'''))"
-}
-cat /proc/loadavg
-run "warm-up" /dev/shm/dpx_out.iq
-for rep in 1 2; do
-run "file -> /dev/null, defaults" /dev/null
-run "file -> /dev/null, 16 threads 32M" /dev/null DOPPLER_IO_THREADS=16 DOPPLER_SLAB_BYTES=33554432
-run "file -> /dev/null, 32 threads 32M" /dev/null DOPPLER_IO_THREADS=32 DOPPLER_SLAB_BYTES=33554432
-run "file -> existing tmpfs file, defaults" /dev/shm/dpx_out.iq
-run "file -> existing tmpfs file, 16 thr 32M" /dev/shm/dpx_out.iq DOPPLER_IO_THREADS=16 DOPPLER_SLAB_BYTES=33554432
-rm -f /dev/shm/dpx_out2.iq
-run "file -> fresh tmpfs file, 16 thr 32M" /dev/shm/dpx_out2.iq DOPPLER_IO_THREADS=16 DOPPLER_SLAB_BYTES=33554432
-run "file -> fresh tmpfs file, 16 thr 32M, pwrite" /dev/shm/dpx_out2.iq DOPPLER_IO_THREADS=16 DOPPLER_SLAB_BYTES=33554432 DOPPLER_NO_MMAP=1
-done
-rm -f $F /dev/shm/dpx_out.iq /dev/shm/dpx_out2.iq
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
