@@ -120,17 +120,21 @@ typedef struct dpx_stream_stats {
 } dpx_stream_stats;
 int dpx_stream_get_stats(const dpx_stream *s, dpx_stream_stats *out);
 
-/* How the slabs of a ring cross PCIe — for the same-process A/B behind the default (profiles/r06_ring.md); never changes a byte.
+/* How the slabs of a ring cross PCIe — for the same-process A/B behind the defaults (profiles/r06_ring.md); never changes a byte.
+ *   DPX_STREAM_PATH_DEFAULT     by slab size, the path that measured fastest: DIRECT below 1 MiB, DIRECT_OUT below 4 MiB, STAGED from there
  *   DPX_STREAM_PATH_DIRECT      the fused kernel loads from the pinned input slab and stores to the pinned output slab
- *                               (host-mapped memory): no HBM staging, no copy engine, one launch per slab   [the default]
- *   DPX_STREAM_PATH_STAGED      copy engine H2D -> kernel HBM to HBM -> copy engine D2H on the slab's stream (rounds 2-5)
+ *                               (host-mapped memory): no HBM staging, no copy engine, one launch per slab (13 us per 8 KiB slab)
+ *   DPX_STREAM_PATH_STAGED      copy engine H2D -> kernel HBM to HBM -> copy engine D2H: every H2D of a GPU on its `up` stream, every
+ *                               D2H on `down` (handed to the runtime one at a time: DPX_STREAM_UNPACED queues them all at submit),
+ *                               launches on `run`; the three streams are probed for a shared hardware queue when the ring is made
+ *                               (DPX_STREAM_NO_PROBE skips that).  45.6-47.5 GB/s each way at 16-64 MiB slabs: 0.98 of the link
  *   DPX_STREAM_PATH_DIRECT_IN   kernel loads from the host slab, output staged;  _DIRECT_OUT: input staged, kernel stores to host
+ *   DPX_STREAM_PATH_STAGED_PER_SLAB   rounds 2-5: H2D -> kernel -> D2H on one stream per slab (28-33 GB/s: the copies take turns)
  *   | DPX_STREAM_COPY_ONLY      calibration: the same slabs on the same path without arithmetic (a plain copy kernel on the
- *                               kernel's side of the link, nothing at all between the two engine copies of STAGED): the
- *                               rate the link gives THIS ring — the `peak` of bench.py's extra.stream_ring
+ *                               kernel's side of the link, nothing at all between the two engine copies of STAGED)
  * in/out_host_flags: extra hipHostMalloc flags of the input / output slabs (hipHostMallocNonCoherent 0x80000000,
  * hipHostMallocWriteCombined 0x4, hipHostMallocNumaUser 0x20000000).
- * opt == NULL: the defaults (path from DPX_STREAM_PATH in the environment when set). */
+ * opt == NULL: the defaults (path from DPX_STREAM_PATH, gather from DPX_STREAM_GATHER in the environment when set). */
 #define DPX_STREAM_PATH_DEFAULT 0u
 #define DPX_STREAM_PATH_DIRECT 1u
 #define DPX_STREAM_PATH_STAGED 2u
