@@ -36,8 +36,9 @@ bool is_reset(float ratio, uint32_t n)
 }
 
 // The scan, candidate by candidate — the definition of the counter rule's reset points, the planner's whole cost in rounds
-// 1-5, and since round 6 what find_reset() is held against and falls back to for counters from 2^24 on.  Where the host has
-// AVX2 it runs eight candidates per instruction in blocks, and only a block that holds a reset is looked at candidate by candidate.  Every
+// 1-5, and since round 6 what find_reset() is held against.  Where the host has
+// AVX2 it runs eight candidates per instruction in blocks, and only a block that holds a reset is looked at candidate by candidate.
+// (The library itself no longer calls it: dpx_find_reset_scan exports it for the comparison.)  Every
 // candidate still gets exactly the reference's arithmetic: fl32(ratio * fl32(n)) — one IEEE multiply per lane, the
 // int -> f32 conversion in the current (nearest-even) rounding mode — and the same test as product_is_integer().
 __attribute__((target("avx2")))
@@ -99,8 +100,9 @@ bool find_reset_scan(float ratio, uint32_t n_start, uint64_t max_scan, uint32_t 
 // the Euclid-like descent of first_in_window() below, O(log Q) steps whatever the period.  At most ~25 binades lie
 // between n_start and X >= 2^23; binades in which even the best approximation so far (the remainder sequence of
 // Euclid's algorithm on (Q, a): |q_i a - p_i Q|, the smallest distance any n < q_(i+1) reaches) stays outside the
-// tolerance are skipped without a descent.  Beyond 2^24 (ratios below ~3e-8 with nothing found yet: a shift of
-// centihertz at megasamples per second) the counter itself is rounded and the SIMD scan above takes over.
+// tolerance are skipped without a descent.  From 2^24 on (ratios below ~3e-8 with nothing found yet: a shift of
+// centihertz at megasamples per second) the counter itself is rounded first; the same search then runs over its 24-bit
+// significand, binade of the counter by binade (first_reset_exact).  No candidate is ever tried one by one.
 // find_reset_scan is the definition; tests/cpp/test_planner_fuzz.cpp and tests/test_host_logic.py hold the two against
 // each other (every start below 2^24 of selected ratios, random ratios of every exponent, ties, subnormals, overflow).
 typedef unsigned __int128 u128;
@@ -124,37 +126,19 @@ static uint64_t first_in_window(uint64_t a, uint64_t m, uint64_t l, uint64_t r, 
     return x <= cap ? (uint64_t)x : kNone;
 }
 
-// first n in [n_start, end) with n < 2^24 and fl32(ratio * n) an integer; *beyond = true when the search has to go on at
-// or past 2^24 (nothing found below; the scan continues there)
-static bool first_reset_exact(float ratio, uint64_t n_start, uint64_t end, uint32_t *n_reset, bool *beyond)
+// smallest m in [lo, hi), hi <= 2^24 + 1, for which the rounding of the exact product X = M m 2^E (M < 2^24) to f32 is an
+// integer by the rule above; kNone if there is none.  *big: the answer is the first m with X >= 2^23 (an integer unless the
+// product overflowed: the caller looks).  m is the counter itself below 2^24 and the counter's 24-bit significand beyond.
+static uint64_t first_integer_product(uint64_t M, int E, uint64_t lo, uint64_t hi, bool *big)
 {
-    *beyond = false;
-    uint32_t bits;
-    memcpy(&bits, &ratio, sizeof bits);
-    const uint32_t ef = (bits >> 23) & 0xffu, frac = bits & 0x7fffffu;
-    if (n_start >= end) return false;
-    if (ef == 0xffu) return false;                       // inf / nan: no product is an integer (0 * inf = nan as well)
-    if (n_start == 0 || (ef == 0 && frac == 0)) {        // n = 0, or ratio = +-0: the product is 0
-        *n_reset = (uint32_t)n_start;
-        return true;
-    }
-    const uint64_t M = ef ? (frac | 0x800000u) : frac;   // |ratio| = M * 2^E
-    const int E = ef ? (int)ef - 150 : -149;
-    constexpr uint64_t kExact = 1ull << 24;              // counters below convert to f32 exactly
-    if (n_start >= kExact) { *beyond = true; return false; }
-    const uint64_t stop = std::min(end, kExact);         // exclusive
-    if (E >= 0) {                                        // every product is an integer; only overflow (monotone in n) prevents a reset
-        if (is_reset(ratio, (uint32_t)n_start)) { *n_reset = (uint32_t)n_start; return true; }
-        return false;                                    // inf from here on, also beyond 2^24
-    }
-    if (-E > 62) {                                       // X < 2^24 * 2^24 * 2^-63: every product below 1/2, no reset below 2^24
-        *beyond = end > kExact;
-        return false;
-    }
+    *big = false;
+    if (lo >= hi) return kNone;
+    if (E >= 0) { *big = true; return lo; }              // every product is an integer of at least 2^23
+    if (-E > 62) return kNone;                           // X < 2^25 * 2^24 * 2^-63: every product below 1/2
     const uint64_t Q = 1ull << -E;
     const uint64_t a = M % Q;
     // remainder sequence of Euclid on (Q, a): rem[i] = |q[i] a - p Q| is the smallest distance to a multiple of Q that any
-    // 1 <= n < q[i+1] reaches
+    // 1 <= m < q[i+1] reaches
     uint64_t qs[96], rems[96];
     int n_conv = 0;
     {
@@ -172,34 +156,77 @@ static bool first_reset_exact(float ratio, uint64_t n_start, uint64_t end, uint3
         rems[n_conv] = r1;
         ++n_conv;
     }
-    uint64_t n = n_start;
+    uint64_t m = lo;
     int conv = 0;
-    while (n < stop) {
-        const uint64_t mn = M * n;                       // < 2^48
-        const int s = 63 - __builtin_clzll(mn);          // floor(log2(M n)); k = s + E
-        if (s + E >= 23) {                               // X >= 2^23: an integer unless it overflowed
-            if (!is_reset(ratio, (uint32_t)n)) return false;
-            *n_reset = (uint32_t)n;
-            return true;
-        }
-        // the binade's last n: M n < 2^(s+1)
-        const uint64_t n_last = std::min<uint64_t>(stop - 1, ((1ull << (s + 1)) - 1) / M);
-        if (s + E < -1) { n = n_last + 1; continue; }    // X < 1/2: no integer within half an ulp
+    while (m < hi) {
+        const uint64_t mm = M * m;                       // < 2^49
+        const int s = 63 - __builtin_clzll(mm);          // floor(log2(M m)); k = s + E
+        if (s + E >= 23) { *big = true; return m; }      // X >= 2^23
+        // the binade's last m: M m < 2^(s+1)
+        const uint64_t m_last = std::min<uint64_t>(hi - 1, ((1ull << (s + 1)) - 1) / M);
+        if (s + E < -1) { m = m_last + 1; continue; }    // X < 1/2: no integer within half an ulp
         const uint64_t T = s >= 24 ? 1ull << (s - 24) : 0;
-        // skip the binade if no n up to its end comes within T of a multiple of Q at all
-        while (conv + 1 < n_conv && qs[conv + 1] <= n_last) ++conv;
-        if (qs[conv] <= n_last && rems[conv] > T && conv + 1 < n_conv) { n = n_last + 1; continue; }
-        const uint64_t b = (uint64_t)(((u128)a * n + T) % Q);
+        // skip the binade if no m up to its end comes within T of a multiple of Q at all
+        while (conv + 1 < n_conv && qs[conv + 1] <= m_last) ++conv;
+        if (qs[conv] <= m_last && rems[conv] > T && conv + 1 < n_conv) { m = m_last + 1; continue; }
+        const uint64_t b = (uint64_t)(((u128)a * m + T) % Q);
         uint64_t x;
         if (b <= 2 * T) x = 0;
-        else x = first_in_window(a, Q, Q - b, Q - b + 2 * T, n_last - n);
-        if (x != kNone && x <= n_last - n) {
-            *n_reset = (uint32_t)(n + x);
+        else x = first_in_window(a, Q, Q - b, Q - b + 2 * T, m_last - m);
+        if (x != kNone && x <= m_last - m) return m + x;
+        m = m_last + 1;
+    }
+    return kNone;
+}
+
+// first n in [n_start, end), end <= 2^32, with fl32(ratio * fl32(n)) an integer.  Below 2^24 the counter is the multiplicand;
+// from 2^24 on it is rounded first (to nearest, ties to even): in the binade [2^(23+j), 2^(24+j)) the multiplicand is
+// c 2^j with c = RNE(n / 2^j) in [2^23, 2^24], so the same search runs over c with the exponent E + j, and the first counter
+// that rounds to the c it finds is c 2^j - 2^(j-1) (+ 1 when c is odd: the tie goes to the even neighbour).
+static bool first_reset_exact(float ratio, uint64_t n_start, uint64_t end, uint32_t *n_reset)
+{
+    uint32_t bits;
+    memcpy(&bits, &ratio, sizeof bits);
+    const uint32_t ef = (bits >> 23) & 0xffu, frac = bits & 0x7fffffu;
+    if (n_start >= end) return false;
+    if (ef == 0xffu) return false;                       // inf / nan: no product is an integer (0 * inf = nan as well)
+    if (n_start == 0 || (ef == 0 && frac == 0)) {        // n = 0, or ratio = +-0: the product is 0
+        *n_reset = (uint32_t)n_start;
+        return true;
+    }
+    const uint64_t M = ef ? (frac | 0x800000u) : frac;   // |ratio| = M * 2^E
+    const int E = ef ? (int)ef - 150 : -149;
+    constexpr uint64_t kExact = 1ull << 24;              // counters below convert to f32 exactly
+    uint64_t n = n_start;
+    bool big = false;
+    if (n < kExact) {
+        const uint64_t m = first_integer_product(M, E, n, std::min(end, kExact), &big);
+        if (m != kNone) {
+            if (big && !is_reset(ratio, (uint32_t)m)) return false;      // overflowed: inf from here on (the product grows with n)
+            *n_reset = (uint32_t)m;
             return true;
         }
-        n = n_last + 1;
+        n = kExact;
     }
-    *beyond = end > kExact && n >= kExact;
+    for (int j = 1; j <= 8 && n < end; ++j) {
+        const uint64_t top = 1ull << (24 + j), h = 1ull << (j - 1);     // the binade's end; half a step of the rounded counter
+        if (n >= top) continue;
+        auto significand = [&](uint64_t v) {             // RNE(v / 2^j)
+            const uint64_t c = v >> j, rem = v & ((1ull << j) - 1);
+            return c + (rem > h || (rem == h && (c & 1u)) ? 1u : 0u);
+        };
+        const uint64_t last = std::min(end, top) - 1;    // the binade's last counter in the window
+        const uint64_t c_lo = significand(n), c_hi = significand(last) + 1;
+        const uint64_t c = first_integer_product(M, E + j, c_lo, c_hi, &big);
+        if (c != kNone) {
+            const uint64_t first_n = (c << j) - h + ((c & 1u) ? 1u : 0u);  // the smallest counter that rounds to c 2^j
+            const uint64_t m = std::max(n, first_n);
+            if (big && !is_reset(ratio, (uint32_t)m)) return false;
+            *n_reset = (uint32_t)m;
+            return true;
+        }
+        n = top;
+    }
     return false;
 }
 
@@ -207,12 +234,7 @@ bool find_reset(float ratio, uint32_t n_start, uint64_t max_scan, uint32_t *n_re
 {
     const uint64_t to_wrap = (1ULL << 32) - (uint64_t)n_start;
     const uint64_t span = std::min(max_scan, to_wrap);
-    const uint64_t end = (uint64_t)n_start + span;
-    bool beyond = false;
-    if (first_reset_exact(ratio, n_start, end, n_reset, &beyond)) return true;
-    if (!beyond) return false;
-    const uint64_t from = std::max<uint64_t>(n_start, 1ull << 24);
-    return find_reset_scan(ratio, (uint32_t)from, end - from, n_reset);
+    return first_reset_exact(ratio, n_start, (uint64_t)n_start + span, n_reset);
 }
 
 // first reset from counter 1 on, remembered per ratio (bit pattern): the period of every steady stretch with that ratio.

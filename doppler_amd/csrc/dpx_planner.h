@@ -25,8 +25,8 @@ bool is_reset(float ratio, uint32_t n);
 
 // first n in [n_start, n_start + max_scan) (not past 2^32-1) with is_reset; false if none
 bool find_reset(float ratio, uint32_t n_start, uint64_t max_scan, uint32_t *n_reset);
-// the same by trying every candidate (AVX2 where the host has it): the definition find_reset is held against, and what
-// find_reset itself falls back to for counters from 2^24 on
+// the same by trying every candidate (AVX2 where the host has it): the definition find_reset is held against
+// (tests/cpp/test_find_reset.cpp); the library itself no longer calls it
 bool find_reset_scan(float ratio, uint32_t n_start, uint64_t max_scan, uint32_t *n_reset);
 
 struct TableBuild {     // one corrector table to fill at plan time

@@ -19,9 +19,10 @@ extern "C" {
  * Closed form of the counter rule dsp.rs:125-130 (pure host integer/f32 code). */
 
 /* first n in [n_start, n_start + max_scan) with fract(fl32(ratio*fl32(n))) == 0; *found = 0 if none in range.
- * ratio = shift_hz/(f32)samplerate.  Since round 6 without a scan for counters below 2^24 (an Euclid-like descent per
- * binade of the product: csrc/dpx_planner.cpp, ~0.4 us whatever the period); dpx_find_reset_scan tries every candidate
- * (the definition: rounds 1-5's implementation, kept as the checker and for counters from 2^24 on). */
+ * ratio = shift_hz/(f32)samplerate.  Since round 6 computed, not searched: an Euclid-like descent per binade of the product
+ * (and, from 2^24 on where the counter is rounded before the multiply, per binade of the counter): csrc/dpx_planner.cpp,
+ * ~0.4 us whatever the period.  dpx_find_reset_scan tries every candidate — the definition, rounds 1-5's implementation,
+ * kept as the checker; the library itself no longer calls it. */
 int dpx_find_reset(float shift_hz, uint32_t samplerate, uint32_t n_start, uint64_t max_scan,
                    uint32_t *n_reset, int *found);
 int dpx_find_reset_scan(float shift_hz, uint32_t samplerate, uint32_t n_start, uint64_t max_scan,

@@ -91,6 +91,27 @@ int main(int argc, char **argv)
         const uint64_t span = 1 + rnd() % ((rnd() & 3) ? 300000 : 3000000);
         if (!check(ratio, start, span, "random")) return 1;
     }
+    // ---- counters from 2^24 on (the counter itself is rounded before the multiply): small ratios whose first reset lies
+    // there, starts anywhere up to 2^32, windows that end before / at / after the reset and across binades of the counter
+    for (int i = 0; i < 1500 * scale; ++i) {
+        const int e = -36 + (int)(rnd() % 14);                  // 2^-36 .. 2^-23: first resets between ~2^20 and 2^29
+        const float ratio = from_bits(((uint32_t)(rnd() & 1) << 31) | ((uint32_t)(e + 127) << 23) | (uint32_t)(rnd() & 0x7fffff));
+        uint32_t start;
+        switch (rnd() % 5) {
+        case 0: start = 1; break;
+        case 1: start = (1u << 24) - 3 + (uint32_t)(rnd() % 6); break;
+        case 2: start = (1u << (24 + rnd() % 8)) - 5 + (uint32_t)(rnd() % 10); break;
+        case 3: start = (uint32_t)(rnd() % 0xffffffffu); break;
+        default: start = (1u << 24) + (uint32_t)(rnd() % (1u << 26)); break;
+        }
+        const uint64_t span = 1 + rnd() % ((i % 7 == 0) ? 90000000ull : 3000000ull);
+        if (!check(ratio, start, span, "counters beyond 2^24")) return 1;
+    }
+    for (uint32_t bits : {0x33000000u, 0x32ffffffu, 0x33000001u, 0x2f800000u, 0x30c90fdbu, 0x4b000000u, 0x3f800000u, 0x3e99999au, 0x7f7fffffu, 0x00000001u})
+        for (uint32_t start : {(1u << 24), (1u << 24) + 1, (1u << 25) - 1, (1u << 25), (1u << 25) + 1, (1u << 25) + 2, (1u << 25) + 3, (1u << 31) - 2, (1u << 31) + 128,
+                               0xffffff00u, 0xffffffffu, 0xfffffffeu})
+            for (uint64_t span : {1ull, 2ull, 3ull, 5ull, 300ull, 100000ull})
+                if (!check(from_bits(bits), start, span, "rounded counters, short windows")) return 1;
     // ---- the shifts a receiver really sees: |hz| < 50 kHz with a fractional part, the usual rates
     const uint32_t rates[] = {8000, 48000, 256000, 300000, 1024000, 2400000};
     for (int i = 0; i < 30000 * scale; ++i) {

@@ -271,10 +271,11 @@ def test_planner_fuzz_under_sanitizers():
 
 
 def test_closed_form_first_reset_equals_the_candidate_scan():
-    """tests/cpp/test_find_reset.cpp: dpx::find_reset (round 6: an Euclid-like descent per binade of the product, no scan below
-    2^24) against dpx::find_reset_scan (every candidate tried with the arithmetic of dsp.rs:125-130) on ~280 000 queries —
+    """tests/cpp/test_find_reset.cpp: dpx::find_reset (round 6: an Euclid-like descent per binade of the product — and of the
+    counter, from 2^24 on — no candidate tried) against dpx::find_reset_scan (every candidate tried with the arithmetic of
+    dsp.rs:125-130) on ~286 000 queries —
     named ratios from every start, random ratios of every exponent and sign, exact ties and their neighbours, dyadic
-    ratios, subnormals, overflow, zero / inf / nan, windows across 2^24."""
+    ratios, subnormals, overflow, zero / inf / nan, small ratios whose first reset lies beyond 2^24 from starts up to 2^32."""
     import subprocess
     r = subprocess.run(["make", "-C", ROOT, "tests/cpp/test_find_reset"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-1500:]
