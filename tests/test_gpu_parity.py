@@ -803,6 +803,25 @@ def test_random_cases_against_oracle(ctx, orc):
         assert_same_bytes(got, want, outtype, "random case %d %r" % (case, segs))
 
 
+def test_first_reset_beyond_2_24(ctx, orc):
+    """A shift of 0.02 Hz at 1.024 Msps: the counter runs to 51 199 998 before its first reset — past 2^24, where it is rounded
+    before the multiply (fl32(n): steps of 2, then 4) and the closed form works on its significand (dpx_planner.cpp,
+    first_reset_exact).  60 M samples: the linear run, the reset, the periodic stretch after it — against the oracle's
+    sequential counter, and the stretch list against the candidate scan."""
+    import doppler_amd
+    from doppler_amd import engine
+    rate, hz, n = 1024000, 0.02, 60_000_000
+    assert engine.find_reset(hz, rate, 1, 1 << 30) == engine.find_reset_scan(hz, rate, 1, 1 << 27) == 51199998
+    st, fin = doppler_amd.plan_describe([(n, hz)], rate, 0)
+    assert [(s["first"], s["count"], s["n_start"], s["period"]) for s in st] == [(0, 1, 0, 0), (1, n - 1, 1, 51199998)], st
+    assert fin == (n - 1) % 51199998 + 1
+    x = make_iq("i16", n, 2424)
+    got, sn = run_bulk(ctx, x, "i16", "i16", [(n, hz)], rate)
+    want, sn_want = orc.segments_stream(x, "i16", "i16", [(n, hz)], rate, threads=16)
+    assert sn == sn_want == fin
+    assert_same_bytes(got, want, "i16", "first reset beyond 2^24")
+
+
 def test_c_abi_error_paths(ctx):
     """Bad arguments come back as error codes with a message, never as a crash or a silent fallback."""
     import ctypes as C
