@@ -298,7 +298,7 @@ def drive_ring(ctxs, slab_bytes, n_slabs, total_bytes, fill, check=None, warm_s=
             st.release()
 
         def cycle(stop):
-            """keeps the ring full until stop(done) says so; returns the completion times of the slabs handed back"""
+            """keeps the ring full until stop(done, seconds) says so, then drains it; returns the times at which the slabs came back"""
             for _ in range(ring):
                 st.acquire()
             t0 = time.perf_counter()
@@ -309,7 +309,7 @@ def drive_ring(ctxs, slab_bytes, n_slabs, total_bytes, fill, check=None, warm_s=
                 st.next_view()
                 st.release()
                 stamps.append(time.perf_counter() - t0)
-                if not stop(len(stamps), stamps[-1]) and submitted < (1 << 40):
+                if not stop(len(stamps), stamps[-1]):
                     st.acquire()
                     st.submit(slab_bytes, segs)
                     submitted += 1
