@@ -233,6 +233,7 @@ RING_WARM_S = 0.6               # untimed cycling before a ring measurement
 PRODUCT_RING_SLAB_BYTES = 64 << 20   # N > 1: the N-device ring rank 0 runs after the gather leg (gather.product_ring)
 PRODUCT_RING_SLABS = 3               # per GPU
 PRODUCT_RING_S = 2.0
+PRODUCT_RING_DEADLINE_S = 60         # per form of the shipped ring (neither has ever run between two physical devices)
 
 
 def link_duplex(dev, nbytes, reps):
@@ -665,6 +666,7 @@ def main():
         LEGS["sustained"] = round(time.perf_counter() - t_leg, 3)
 
     # ---- outside the timed region: ordered gather (multi-GPU), host round trip, CPU baseline
+    hard_exit = False
     gather = None
     t_leg = time.perf_counter()
     if DIST_ON:
@@ -757,28 +759,50 @@ def main():
                 store = None
             if rank == 0:
                 devices = [0] * world if share else list(range(world))
-                try:
-                    gather["product_ring"] = product_ring(devices)
-                except Exception as e:
-                    gather["product_ring"] = {"error": str(e)[:300]}
+
+                def guarded(key, **kw):
+                    """one form of the shipped ring in a thread of its own with a deadline: neither form has ever run between two
+                    physical devices — a ring that does not come back is reported as such and the line is printed without it"""
+                    box = {}
+
+                    def work():
+                        try:
+                            box["r"] = product_ring(devices, **kw)
+                        except Exception as e:
+                            box["r"] = {"error": str(e)[:300]}
+
+                    th = threading.Thread(target=work, daemon=True)
+                    th.start()
+                    th.join(PRODUCT_RING_DEADLINE_S)
+                    if th.is_alive():
+                        gather[key] = {"error": "did not come back within %d s" % PRODUCT_RING_DEADLINE_S}
+                        return False
+                    gather[key] = box["r"]
+                    return True
+
+                ok = guarded("product_ring")
                 # the same ring with the gather BASELINE.json's north_star names (`doppler --gather rccl`): outputs of GPUs
                 # 1..N-1 over RCCL into GPU 0, from there to the host.  Needs distinct devices (one communicator rank each).
-                if len(set(devices)) == len(devices):
-                    try:
-                        gather["product_ring_rccl"] = product_ring(devices, gather="rccl")
-                    except Exception as e:
-                        gather["product_ring_rccl"] = {"error": str(e)[:300]}
+                if not ok:
+                    gather["product_ring_rccl"] = {"skipped": "the per-GPU form did not come back"}
+                elif len(set(devices)) == len(devices):
+                    ok = guarded("product_ring_rccl", gather="rccl")
                 else:
                     gather["product_ring_rccl"] = {"skipped": "the ranks share one GPU (development mode): RCCL needs one device per rank"}
+                hard_exit = not ok            # a ring thread is still stuck inside the runtime: no collective after this, the process leaves by os._exit
                 if store is not None:
+                    if hard_exit:
+                        store.set("dpx_hard_exit", "1")
                     store.set("dpx_product_ring_done", "1")
             elif store is not None:
                 import datetime
                 try:
                     store.wait(["dpx_product_ring_done"], datetime.timedelta(seconds=GATHER_TIMEOUT_S))
+                    hard_exit = store.check(["dpx_hard_exit"])
                 except Exception:
                     pass
-            barrier()
+            if not hard_exit:
+                barrier()
         gather_state["done"] = True
         timer.cancel()
         LEGS["gather"] = round(time.perf_counter() - t_leg, 3)
@@ -840,6 +864,9 @@ def main():
         result["legs_s"] = dict(LEGS)
         print(json.dumps(result), flush=True)
 
+    if hard_exit:                 # (see the product ring leg: a stuck ring thread on rank 0; the line above is already out)
+        sys.stdout.flush()
+        os._exit(0)
     plan.close()
     if DIST_ON:
         dist.barrier()
