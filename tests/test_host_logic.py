@@ -282,6 +282,17 @@ def test_closed_form_first_reset_equals_the_candidate_scan():
     r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_find_reset"), "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "equal to the scan" in r.stdout
+    # and once more under AddressSanitizer + UBSan: the descent shifts by computed amounts and multiplies into 128 bits
+    exe = os.path.join(ROOT, "tests", "cpp", "test_find_reset_san")
+    csrc = os.path.join(ROOT, "doppler_amd", "csrc")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-ffp-contract=off",
+                        "-fno-fast-math", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_find_reset.cpp"),
+                        os.path.join(csrc, "dpx_planner.cpp"), os.path.join(csrc, "dpx_simulate.cpp")], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in (r.stderr + r.stdout):
+        return                                         # no sanitizer runtime for g++ here: the plain run above stands
+    assert r.returncode == 0, r.stderr[-1500:]
+    r = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "equal to the scan" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
 def test_chunk_sharding_seeds(orc):
